@@ -1,0 +1,450 @@
+"""GPU parity: every HIP kernel, called through the C ABI, against the CPU oracle on the
+same inputs.  Integer/byte/index results must be identical; float results carry the
+tolerance written next to each check."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import modem_oracle as mo
+from wavenet_amd import _lib as L
+from wavenet_amd import modem as M
+
+pytestmark = pytest.mark.gpu
+
+SB, SA = mo.scheme_b(), mo.scheme_a()
+MAC_O, MAC_D = bytes.fromhex("aabbccddeeff"), bytes.fromhex("112233445566")
+
+
+@pytest.fixture(scope="module")
+def mb():
+    return M.Modem(M.esquema_b())
+
+
+@pytest.fixture(scope="module")
+def ma():
+    return M.Modem(M.esquema_a())
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rows_from(frames, stride):
+    buf = np.zeros((len(frames), stride), dtype=np.uint8)
+    lens = np.zeros(len(frames), dtype=np.int32)
+    for i, f in enumerate(frames):
+        buf[i, :len(f)] = np.frombuffer(bytes(f), dtype=np.uint8)
+        lens[i] = len(f)
+    return buf, lens
+
+
+# ------------------------------------------------------------------------------- MFMA layout
+def test_mfma_lane_layout(mb):
+    """v_mfma_f32_16x16x4_f32: lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; register r of
+    lane l holds D[4*(l>>4)+r][l&15].  The detection kernel is built on exactly this."""
+    d = mb.selftest_mfma()
+    i = np.arange(16)
+    A = 1.0 + i[:, None] + 16.0 * np.arange(4)[None, :]
+    B = 1.0 + 3.0 * i[None, :] + 100.0 * np.arange(4)[:, None]
+    D = A @ B
+    for lane in range(64):
+        for r in range(4):
+            assert d[lane, r] == D[4 * (lane >> 4) + r, lane & 15], (lane, r)
+
+
+# ------------------------------------------------------------------------------- K4
+@pytest.mark.parametrize("stride", [128, 48, 272, 50])
+def test_crc32_batch(mb, stride):
+    rng = np.random.default_rng(stride)
+    n = 3000 + stride
+    buf = rng.integers(0, 256, (n, stride), dtype=np.uint8)
+    lens = rng.integers(0, stride + 1, n).astype(np.int32)
+    lens[:4] = [0, 1, stride, stride - 1]
+    got = mb.crc32(dev(buf), dev(lens)).cpu().numpy()
+    want = np.array([zlib.crc32(buf[i, :lens[i]].tobytes()) for i in range(n)], dtype=np.int64)
+    assert np.array_equal(got, want)
+
+
+def test_crc32_known_answer(mb):
+    buf, lens = rows_from([b"123456789", b""], 16)
+    got = mb.crc32(dev(buf), dev(lens)).cpu().numpy()
+    assert got.tolist() == [0xCBF43926, 0]
+
+
+def test_frame_build_matches_reference_vectors(mb, golden):
+    fr = golden["frames"]
+    fields = np.zeros((len(fr), 16), dtype=np.uint8)
+    pay = np.zeros((len(fr), 112), dtype=np.uint8)
+    for i, f in enumerate(fr):
+        p = bytes.fromhex(f["payload"])
+        fields[i, :15] = np.frombuffer(bytes([f["version"]]) + bytes.fromhex(f["mac_o"]) + bytes.fromhex(f["mac_d"]) +
+                                       bytes([f["tipo"], len(p)]), dtype=np.uint8)
+        pay[i, :len(p)] = np.frombuffer(p, dtype=np.uint8)
+    frames, lens = mb.build_frames(dev(fields), dev(pay), 128)
+    frames, lens = frames.cpu().numpy(), lens.cpu().numpy()
+    for i, f in enumerate(fr):
+        assert bytes(frames[i, :lens[i]]).hex() == f["frame"]
+        assert not frames[i, lens[i]:].any()
+
+
+def test_frame_build_rejects_rows_that_do_not_fit(mb):
+    fields = np.zeros((2, 16), dtype=np.uint8)
+    fields[0, 14] = 200     # 219 bytes do not fit a 128-byte row
+    fields[1, 14] = 3
+    pay = np.zeros((2, 256), dtype=np.uint8)
+    _, lens = mb.build_frames(dev(fields), dev(pay), 128)
+    assert lens.cpu().tolist() == [-1, 22]
+
+
+def test_frame_parse_validate(mb, golden):
+    cases = golden["parse_cases"]
+    raws = [bytes.fromhex(c["raw"]) for c in cases]
+    buf, lens = rows_from(raws, 288)
+    rec = M.Modem.records_to_numpy(mb.parse_frames(dev(buf), dev(lens)))
+    msg = {L.ST_EMPTY: mo.PARSE_MESSAGES[mo.ST_EMPTY], L.ST_SHORT_HEADER: mo.PARSE_MESSAGES[mo.ST_SHORT_HEADER],
+           L.ST_SHORT_BODY: mo.PARSE_MESSAGES[mo.ST_SHORT_BODY]}
+    for c, raw, r in zip(cases, raws, rec):
+        if c["error"] is None:
+            assert r["status"] == L.ST_OK, c["name"]
+            assert (int(r["tipo"]), int(r["length"]), bool(r["crc_ok"])) == (c["tipo"], c["length"], c["crc_ok"])
+            assert int(r["crc"]) == zlib.crc32(raw[:15 + c["length"]])
+        else:
+            assert msg[int(r["status"])] == c["error"], c["name"]
+
+
+def test_frame_parse_random_mixed(mb):
+    """Mixed payload lengths 0..107, 1 % corrupted: the shape of the checksum microbenchmark."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    frames = []
+    for i in range(n):
+        ln = int(rng.integers(0, 108))
+        f = bytearray(mo.build_frame(1, rng.bytes(6), rng.bytes(6), 3, rng.bytes(ln)))
+        if rng.random() < 0.01:
+            f[int(rng.integers(0, len(f)))] ^= 1 << int(rng.integers(0, 8))
+        frames.append(bytes(f))
+    buf, lens = rows_from(frames, 128)
+    rec = M.Modem.records_to_numpy(mb.parse_frames(dev(buf), dev(lens)))
+    for f, r in zip(frames, rec):
+        st = mo.parse_status(f)
+        assert int(r["status"]) == st
+        if st == mo.ST_OK:
+            p = mo.parse_frame(f)
+            assert bool(r["crc_ok"]) == p.crc_ok and int(r["crc"]) == zlib.crc32(f[:15 + p.length])
+
+
+# ------------------------------------------------------------------------------- K1
+def test_synth_live_matches_reference_audio(mb, golden):
+    """float32 samples = the reference's float64 samples rounded, up to the reference's own
+    phase rounding: |diff| <= half a float32 ulp + 5e-11."""
+    frames = [bytes.fromhex(golden["frames"][0]["frame"]), bytes.fromhex(golden["frames"][1]["frame"]),
+              mo.build_frame(1, bytes(6), bytes(6), 3, bytes([7, 7, 7, 9, 9, 0, 0, 0, 0])),
+              bytes.fromhex(golden["prueba_on_air_frames"][2])]
+    buf, lens = rows_from(frames, 128)
+    stride = M.pad4(max(len(mo.emit_frame(f, SB)) for f in frames) + 1000)
+    audio, n_samples = mb.encode_streams(dev(buf), dev(lens), stride)
+    audio, n_samples = audio.cpu().numpy(), n_samples.cpu().numpy()
+    for i, f in enumerate(frames):
+        ref = mo.emit_frame(f, SB)
+        assert n_samples[i] == len(ref)
+        got = audio[i, :len(ref)].astype(np.float64)
+        half_ulp = 0.5 * np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+        assert np.all(np.abs(got - ref) <= half_ulp * 1.0001 + 5e-11)
+        assert not audio[i, len(ref):].any()          # zero fill to the end of the slot
+    # spot values the reference itself produced
+    t = golden["tones_b"][0]       # the 250 Hz ping opens every frame
+    assert np.allclose(audio[0, t["idx"][:16]], t["samples"][:16], rtol=0, atol=6e-8)
+
+
+def test_synth_sample_counts_with_repeats(mb, golden):
+    frames = [bytes.fromhex(c["frame"]) for c in golden["sample_counts_b"]]
+    buf, lens = rows_from(frames, 128)
+    lay = mb.layout(dev(buf), dev(lens))
+    assert lay[3].cpu().tolist() == [c["n_samples"] for c in golden["sample_counts_b"]]
+
+
+def test_synth_unaligned_destination_and_no_fill(mb):
+    f = mo.build_frame(1, MAC_O, MAC_D, 1, b"")
+    buf, lens = rows_from([f, f], 32)
+    lay = mb.layout(dev(buf), dev(lens))
+    n = int(lay[3][0])
+    audio = torch.full((2 * n + 64,), 7.0, dtype=torch.float32, device="cuda")
+    dst = torch.tensor([3, n + 10], dtype=torch.int64, device="cuda")
+    mb.synth(lay, dst, audio, M.pad4(n))
+    a = audio.cpu().numpy()
+    ref = mo.emit_frame(f, SB).astype(np.float32)
+    assert np.all(a[:3] == 7.0) and np.all(a[n + 3:n + 10] == 7.0) and np.all(a[2 * n + 10:] == 7.0)
+    assert np.max(np.abs(a[3:n + 3] - ref)) <= 6e-8 and np.max(np.abs(a[n + 10:2 * n + 10] - ref)) <= 6e-8
+
+
+def test_synth_wav_int16(mb, ma, golden):
+    g = golden["wav_b"]
+    f = bytes.fromhex(g["frame"])
+    buf, lens = rows_from([f], 32)
+    audio, n = mb.encode_streams(dev(buf), dev(lens), M.pad4(g["n"]), variant=L.EMIT_WAV, dtype=torch.int16)
+    w = audio.cpu().numpy()[0, :g["n"]]
+    assert int(n[0]) == g["n"] and np.array_equal(w, mo.wav_int16(f, SB))
+    assert w[:32].tolist() == g["head"] and w[-32:].tolist() == g["tail"]
+    g = golden["wav_a"]
+    msg = bytes.fromhex(g["message"])
+    buf, lens = rows_from([msg], 128)
+    audio, n = ma.encode_streams(dev(buf), dev(lens), M.pad4(g["n"]), variant=L.EMIT_WAV, dtype=torch.int16)
+    w = audio.cpu().numpy()[0, :g["n"]]
+    assert int(n[0]) == g["n"] and np.array_equal(w, mo.wav_int16(msg, SA))
+
+
+def test_synth_scheme_a_live(ma, golden):
+    g = golden["capa1_main_audio"]
+    frames = [bytes.fromhex(x) for x in g["frames"]]
+    buf, lens = rows_from(frames, 128)
+    stride = M.pad4(127 * 2205)
+    audio, n = ma.encode_streams(dev(buf), dev(lens), stride)
+    audio = audio.cpu().numpy()
+    for i, f in enumerate(frames):
+        ref = np.concatenate([mo.tone(fr, nn, d, SA) for fr, nn, d in mo.schedule(f, SA)])
+        assert int(n[i]) == len(ref)
+        assert np.max(np.abs(audio[i, :len(ref)] - ref)) <= 3e-8 + 5e-11
+
+
+# ------------------------------------------------------------------------------- K2
+def oracle_windows(x32, esq_cls, n):
+    bins, mags = mo.window_bins(x32.astype(np.float64), n)
+    return bins, mags, esq_cls[bins]
+
+
+def capture_of(s):
+    parts = []
+    for raw, gap in zip(s["frames"], s["gaps"]):
+        parts += [np.zeros(gap), mo.emit_frame(bytes.fromhex(raw), SB)]
+    x = np.concatenate(parts)
+    if s["sigma"] > 0:
+        x = x + s["sigma"] * np.random.default_rng(s["seed"]).standard_normal(len(x))
+    return x
+
+
+def check_detect(m, x32, n, lut, mag_rtol=1e-4):
+    nwin = len(x32) // n
+    pad = np.zeros(M.pad4(nwin * n), dtype=np.float32)
+    pad[:nwin * n] = x32[:nwin * n]
+    cls, mag, kbin = m.detect(dev(pad), 1, len(pad), nwin)
+    cls, mag, kbin = cls.cpu().numpy()[0], mag.cpu().numpy()[0], kbin.cpu().numpy()[0]
+    obins, omags, ocls = oracle_windows(pad[:nwin * n], lut, n)
+    assert np.array_equal(kbin, obins)
+    assert np.array_equal(cls.astype(np.uint16), ocls)
+    nz = omags > 0
+    assert np.all(np.abs(mag[nz] - omags[nz]) <= mag_rtol * omags[nz])       # tone energies: 1e-4 relative
+    assert np.all(mag[~nz] == 0)
+    return cls
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_detect_reference_scenarios(mb, golden, idx):
+    """Windows of the captures the reference itself decoded (float32 audio): dominant bin,
+    class and magnitude per window, and the bins the reference saw in float64."""
+    s = golden["listen_b"][idx]
+    x = capture_of(s)
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    x32 = x.astype(np.float32)
+    check_detect(mb, x32, 7055, lut)
+    # float32 rounding of the audio does not move the reference's decisions here
+    assert mo.window_bins(x32.astype(np.float64), 7055)[0].tolist() == s["window_bins"]
+
+
+def test_detect_pure_tones_and_silence(mb, golden):
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    parts = [mo.tone(p["freq"], SB.ping_n, mo.BYTE_DURATION * 2, SB)[:7055] for p in golden["pure_windows_b"]]
+    parts.append(np.zeros(7055))
+    parts.append(np.full(7055, 0.25))
+    x32 = np.concatenate(parts).astype(np.float32)
+    cls = check_detect(mb, x32, 7055, lut)
+    for p, c in zip(golden["pure_windows_b"], cls):
+        assert int(c) == p["cls"]
+
+
+def test_detect_noise_only_and_offsets(mb, golden):
+    """Noise-only windows (the reference's argmax is then any bin) at every alignment of the
+    window start modulo 4 samples, several streams."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    rng = np.random.default_rng(11)
+    n_streams, n_windows, first = 5, 9, 3
+    stride = M.pad4(first + n_windows * 7055 + 6)
+    a = (0.1 * rng.standard_normal((n_streams, stride))).astype(np.float32)
+    cls, mag, kbin = mb.detect(dev(a), n_streams, stride, n_windows, first)
+    for s in range(n_streams):
+        ob, om, oc = oracle_windows(a[s, first:first + n_windows * 7055], lut, 7055)
+        assert np.array_equal(kbin[s].cpu().numpy(), ob)
+        assert np.array_equal(cls[s].cpu().numpy().astype(np.uint16), oc)
+        assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
+
+
+def test_detect_refinement_paths_forced(golden):
+    """Raise the tie band so that the float64 re-evaluation runs on ordinary windows: both
+    the two-bin and the whole-spectrum path must reproduce the oracle."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    x = capture_of(golden["listen_b"][1])[:7055 * 24]
+    rng = np.random.default_rng(3)
+    x = np.concatenate([x, 0.1 * rng.standard_normal(7055 * 8)]).astype(np.float32)
+    for band, which in ((0.5, 1), (0.9995, 2)):
+        m = M.Modem(M.esquema_b())
+        m.set_tie_band(band)
+        m.detect_stats()
+        check_detect(m, x, 7055, lut)
+        st = m.detect_stats()
+        assert st[0] == 32 and st[which] + st[2] > 0 and (which == 1 or st[2] >= 30), st   # silent windows need no float64
+
+
+def test_detect_near_tie_decided_in_float64(mb, golden):
+    """Two tones whose peaks are closer than float32 can tell: the float64 path decides as
+    the reference does."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    n = np.arange(7055)
+    k1, k2 = 400, 1400
+    wins = []
+    for eps in (0.0, 1e-7, -1e-7, 3e-6, -3e-6):
+        wins.append(np.cos(2 * np.pi * k1 * n / 7055) + (1.0 + eps) * np.cos(2 * np.pi * k2 * n / 7055 + 0.3))
+    x32 = (0.4 * np.concatenate(wins)).astype(np.float32)
+    mb.detect_stats()
+    check_detect(mb, x32, 7055, lut)
+    assert mb.detect_stats()[1] >= 3
+
+
+def test_detect_scheme_a(ma, golden):
+    lut = np.array(golden["classes_a_2205"], dtype=np.uint16)
+    msg = bytes(range(128))
+    x = np.concatenate([mo.tone(f, n, d, SA) for f, n, d in mo.schedule(msg, SA)]).astype(np.float32)
+    cls = check_detect(ma, x, 2205, lut)
+    assert (cls[:128] & 0x1FF).tolist() == list(range(128))
+    rng = np.random.default_rng(2)
+    check_detect(ma, (x + 0.2 * rng.standard_normal(len(x))).astype(np.float32), 2205, lut)
+
+
+# ------------------------------------------------------------------------------- state machine
+@pytest.mark.parametrize("idx", range(7))
+def test_listen_scenarios_end_to_end(mb, golden, idx):
+    """detect -> slice -> parse on the reference's own scenarios: the same frames (or the
+    same error) call after call, and the same number of windows per call."""
+    s = golden["listen_b"][idx]
+    x32 = capture_of(s).astype(np.float32)
+    nwin = -(-len(x32) // 7055)
+    pad = np.zeros(M.pad4(nwin * 7055), dtype=np.float32)
+    pad[:len(x32)] = x32
+    tw = mb.timeout_windows(s["timeout"])
+    assert tw == mo.timeout_to_windows(s["timeout"], SB)
+    out = mb.decode_streams(dev(pad), 1, len(pad), nwin, s["timeout"], max_calls=len(s["calls"]), frame_cap=288)
+    by, lens = out["bytes"].cpu().numpy()[0], out["lens"].cpu().numpy()[0]
+    start, end = out["start"].cpu().numpy()[0], out["end"].cpu().numpy()[0]
+    rec = M.Modem.records_to_numpy(out["rec"][0])
+    ncalls = int(out["n_calls"][0])
+    for j, call in enumerate(s["calls"]):
+        if j >= ncalls:
+            assert call["oracle_bytes"] == ""       # capture exhausted: nothing left to hear
+            continue
+        got = bytes(by[j, :lens[j]])
+        assert got.hex() == call["oracle_bytes"], (s["name"], j)
+        if end[j] < nwin:
+            assert end[j] - start[j] == call["windows"]
+        if call["error"] is None:
+            assert got.hex() == call["bytes"] and rec[j]["status"] == L.ST_OK and rec[j]["crc_ok"] == 1
+        else:
+            msgs = {L.ST_EMPTY: mo.PARSE_MESSAGES[1], L.ST_SHORT_HEADER: mo.PARSE_MESSAGES[2],
+                    L.ST_SHORT_BODY: mo.PARSE_MESSAGES[3]}
+            assert msgs[int(rec[j]["status"])] == call["error"]
+
+
+def test_slice_random_class_sequences(mb):
+    """The state machine alone on random class words (pings, EOFs, bytes, separators in any
+    order), many streams, several timeouts."""
+    rng = np.random.default_rng(9)
+    n_streams, n_windows = 300, 400
+    pool = np.array([256, 256, 256, 256 | 512, 256 | 1024, 7, 7, 9, 200, 255, 0], dtype=np.uint16)
+    cls = pool[rng.integers(0, len(pool), (n_streams, n_windows))]
+    for tw, max_calls in ((33, 6), (5, 40), (1000, 3)):
+        by, lens, start, end, reason, ncalls = [t.cpu().numpy() for t in
+                                                mb.slice(dev(cls.astype(np.int16)), tw, max_calls, 64)]
+        for s in range(n_streams):
+            want = mo.slice_classes(cls[s], tw, max_calls)
+            assert ncalls[s] == len(want)
+            for j, (w0, w1, b, r) in enumerate(want):
+                assert (start[s, j], end[s, j]) == (w0, w1)
+                assert bytes(by[s, j, :lens[s, j]]) == b[:64]
+                assert (reason[s, j] & 0xFF) == r
+                assert bool(reason[s, j] & L.END_OVERFLOW) == (len(b) > 64)
+
+
+# ------------------------------------------------------------------------------- K3
+def test_sync_scan_energies_and_sound_verdicts(mb, golden):
+    """Energies within 1e-4 relative of the float64 values; a decided verdict is never wrong."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    for idx in (1, 4, 5):
+        s = golden["listen_b"][idx]
+        x32 = capture_of(s).astype(np.float32)
+        nwin = len(x32) // 7055
+        pad = np.zeros(M.pad4(nwin * 7055), dtype=np.float32)
+        pad[:nwin * 7055] = x32[:nwin * 7055]
+        pe, we, vd = [t.cpu().numpy()[0] for t in mb.sync_scan(dev(pad), 1, len(pad), nwin)]
+        xw = pad[:nwin * 7055].astype(np.float64).reshape(nwin, 7055)
+        spec = np.abs(np.fft.fft(xw, axis=1)) ** 2
+        want_pe = spec[:, 39:42].max(axis=1)
+        want_we = (xw ** 2).sum(axis=1)
+        assert np.allclose(we, want_we, rtol=1e-4, atol=1e-12)
+        assert np.all(np.abs(pe - want_pe) <= 1e-4 * want_pe + 1e-6 * (7055 * want_we))
+        is_ping = (lut[np.argmax(spec[:, :3527], axis=1)] & 512) != 0
+        assert np.all(is_ping[vd == 1]) and not np.any(is_ping[vd == 0])
+        if s["sigma"] < 0.5:
+            assert (vd != 2).mean() > 0.9           # clean frames are decided without a spectrum
+    sil = torch.zeros(7056 * 3, dtype=torch.float32, device="cuda")
+    assert mb.sync_scan(sil, 1, 7056 * 3, 3)[2].cpu().tolist() == [[0, 0, 0]]
+
+
+# ------------------------------------------------------------------------------- round trip at scale
+def test_roundtrip_many_streams_max_payload(mb):
+    """Configuration 2 in small: independent streams, one 107-byte frame each, encode on the
+    GPU, decode on the GPU; every frame must come back bit-exact with a valid checksum, and
+    a sample of streams is checked window by window against the oracle."""
+    n = 48
+    rng = np.random.default_rng(21)
+    fields = np.zeros((n, 16), dtype=np.uint8)
+    fields[:, 0] = 1
+    fields[:, 1:13] = rng.integers(0, 256, (n, 12))
+    fields[:, 13] = 3
+    fields[:, 14] = 107
+    pay = rng.integers(0, 256, (n, 112), dtype=np.uint8)
+    pay[3, :107] = 42                      # a stream full of repeated bytes (short separators)
+    frames, lens = mb.build_frames(dev(fields), dev(pay), 128)
+    stride = M.pad4(mb.esquema.max_frame_samples(126))
+    nwin = stride // 7055
+    audio, n_samples = mb.encode_streams(frames, lens, stride)
+    out = mb.decode_streams(audio, n, stride, nwin, 123.0)
+    by, ln = out["bytes"].cpu().numpy()[:, 0], out["lens"].cpu().numpy()[:, 0]
+    rec = M.Modem.records_to_numpy(out["rec"])
+    fr = frames.cpu().numpy()
+    for i in range(n):
+        assert ln[i] == 126 and np.array_equal(by[i, :126], fr[i, :126]), i
+        assert rec[i]["status"] == L.ST_OK and rec[i]["crc_ok"] == 1
+        want = mo.build_frame(1, bytes(fields[i, 1:7]), bytes(fields[i, 7:13]), 3, bytes(pay[i, :107]))
+        assert bytes(fr[i, :126]) == want
+    lut = M.host_class_lut(mb.esquema)
+    a = audio.cpu().numpy()
+    for i in (0, 3, n - 1):
+        ob, om, oc = oracle_windows(a[i, :nwin * 7055], lut, 7055)
+        assert np.array_equal(out["bin"][i].cpu().numpy(), ob)
+        assert np.array_equal(out["cls"][i].cpu().numpy().astype(np.uint16), oc)
+        got, reason, used = mo.listen_frame(mo.Capture(a[i].astype(np.float64)), 123.0, SB)
+        assert bytes(got) == bytes(fr[i, :126]) and reason == mo.R_EOF
+        assert int(out["end"][i, 0]) == used
+
+
+def test_awgn_statistics(mb):
+    a = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
+    mb.awgn(a, 0.1, 1234)
+    x = a.cpu().numpy().astype(np.float64)
+    assert abs(x.mean()) < 1e-3 and abs(x.std() - 0.1) < 1e-3
+    assert abs((np.abs(x) > 0.2).mean() - 0.0455) < 2e-3
+    b = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
+    mb.awgn(b, 0.1, 1234)
+    assert torch.equal(a, b)

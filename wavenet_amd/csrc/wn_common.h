@@ -1,0 +1,64 @@
+// Shared internals of libwavenet_hip.so: the context object and error plumbing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wavenet_hip.h"
+
+struct wn_ctx {
+    wn_scheme s;
+    int device;
+    int num_cus;
+    // synthesis: quarter-wave tables, quarter+1 entries each
+    int32_t quarter;
+    float *d_sin_f32;
+    int16_t *d_sin_i16;
+    // detection: window length n = n1*n2 (coprime, n2 odd), CRT idempotents e1, e2
+    int32_t n, n1, n2, nbins;
+    int32_t e1, e2;
+    uint16_t *d_cls_lut;  // nbins class words
+    float2 *d_tw1;        // n1 entries (cos, sin)(2*pi*m/n1)
+    float2 *d_tw2;        // n2 entries (cos, -sin)(2*pi*m/n2)
+    double tie_band;
+    unsigned long long *d_stats;  // 4 counters
+    // sync: ping bins [lo, hi]
+    int32_t ping_lo, ping_hi;
+    // checksum: slicing-by-4 tables [4][256]
+    uint32_t *d_crc_tab;
+};
+
+void wn_set_error(const char *fmt, ...);
+
+#define WN_HIP_TRY(expr)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            wn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                       \
+            return WN_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define WN_REQUIRE(cond, what)                       \
+    do {                                             \
+        if (!(cond)) {                               \
+            wn_set_error("bad argument: %s", what);  \
+            return WN_ERR_ARG;                       \
+        }                                            \
+    } while (0)
+
+static inline int wn_launch_check(const char *kernel) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        wn_set_error("launch of %s failed: %s", kernel, hipGetErrorString(e));
+        return WN_ERR_HIP;
+    }
+    return WN_OK;
+}
+
+// host tables (wn_ctx.hip)
+void wn_host_crc_tables(uint32_t tab[4][256]);
+int wn_plan_lookup(int32_t n, int32_t *n1, int32_t *n2);
+
+// per-file launchers used by wn_ctx.hip at init time
+int wn_detect_prepare(wn_ctx *ctx);

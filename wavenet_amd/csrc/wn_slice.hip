@@ -1,0 +1,102 @@
+// Receive state machine over window classes.
+//
+// Replaces the loop of escuchar_y_retornar_trama (c1_shared.py:312-351): wait for a
+// ping-class window (B:330-335, which also restarts the timeout clock), stop at an
+// EOF-class window (B:337-339), take a byte-class window as a symbol only after a
+// separator (non-byte) window was seen (expect_silence, B:341-351).  Calls follow each
+// other over one capture the way repeated listen calls consume one audio device: the
+// next call starts at the window after the previous call's last window.
+//
+// For the prototype scheme (no separators, capa1.py has no receive loop) every window is
+// one symbol and a stream yields one record with the byte-class windows in order.
+//
+// One lane per stream: the machine is sequential in the window index and its input is
+// 2 bytes per window, so this kernel is negligible next to detection.
+#include "wn_common.h"
+
+__global__ __launch_bounds__(64) void slice_kernel(const uint16_t *__restrict__ cls, long long n_streams,
+                                                   long long n_windows, int timeout_windows, int max_calls,
+                                                   int frame_cap, int symbol_per_window,
+                                                   uint8_t *__restrict__ out_bytes, int32_t *__restrict__ out_lens,
+                                                   int32_t *__restrict__ out_start, int32_t *__restrict__ out_end,
+                                                   int32_t *__restrict__ out_reason, int32_t *__restrict__ n_calls) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const uint16_t *c = cls + s * n_windows;
+    int calls = 0;
+    long long w = 0;
+    if (symbol_per_window) {
+        uint8_t *ob = out_bytes + (s * max_calls) * (long long)frame_cap;
+        int len = 0, over = 0;
+        for (; w < n_windows; ++w) {
+            const int b = c[w] & WN_CLS_BYTE_MASK;
+            if (b == WN_CLS_NONE) continue;
+            if (len < frame_cap) ob[len++] = (uint8_t)b; else over = WN_END_OVERFLOW;
+        }
+        if (max_calls > 0) {
+            out_lens[s * max_calls] = len;
+            out_start[s * max_calls] = 0;
+            out_end[s * max_calls] = (int32_t)n_windows;
+            out_reason[s * max_calls] = WN_END_TIMEOUT | over;
+            calls = 1;
+        }
+        n_calls[s] = calls;
+        return;
+    }
+    while (w < n_windows && calls < max_calls) {
+        const long long rec = s * max_calls + calls;
+        uint8_t *ob = out_bytes + rec * (long long)frame_cap;
+        const long long start_w = w;
+        long long t0 = w;
+        int len = 0, over = 0;
+        bool heard = false, expect_silence = true;
+        int reason = WN_END_TIMEOUT;
+        while (true) {
+            if (w - t0 >= timeout_windows || w >= n_windows) break;
+            const int cw = c[w];
+            ++w;
+            if (!heard) {
+                if (cw & WN_CLS_PING) {
+                    heard = true;
+                    t0 = w;
+                }
+                continue;
+            }
+            if (cw & WN_CLS_EOF) {
+                reason = WN_END_EOF;
+                break;
+            }
+            const int b = cw & WN_CLS_BYTE_MASK;
+            if (b != WN_CLS_NONE) {
+                if (expect_silence) continue;
+                if (len < frame_cap) ob[len++] = (uint8_t)b; else over = WN_END_OVERFLOW;
+                expect_silence = true;
+            } else {
+                expect_silence = false;
+            }
+        }
+        out_lens[rec] = len;
+        out_start[rec] = (int32_t)start_w;
+        out_end[rec] = (int32_t)w;
+        out_reason[rec] = reason | over;
+        ++calls;
+    }
+    n_calls[s] = calls;
+}
+
+extern "C" int wn_slice_frames(wn_ctx *ctx, const uint16_t *d_cls, int64_t n_streams, int64_t n_windows,
+                               int32_t timeout_windows, int32_t max_calls, int32_t frame_cap, uint8_t *d_bytes,
+                               int32_t *d_lens, int32_t *d_start, int32_t *d_end, int32_t *d_reason,
+                               int32_t *d_n_calls, void *stream) {
+    WN_REQUIRE(ctx && n_streams >= 0 && n_windows >= 0 && n_windows < (1ll << 31), "ctx / sizes");
+    WN_REQUIRE(timeout_windows > 0 && max_calls > 0 && frame_cap > 0, "timeout_windows, max_calls, frame_cap > 0");
+    WN_REQUIRE(n_streams == 0 || (d_bytes && d_lens && d_start && d_end && d_reason && d_n_calls &&
+                                  (d_cls || n_windows == 0)),
+               "null device pointer");
+    if (n_streams == 0) return WN_OK;
+    const unsigned blocks = (unsigned)((n_streams + 63) / 64);
+    hipLaunchKernelGGL(slice_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, d_cls, (long long)n_streams,
+                       (long long)n_windows, (int)timeout_windows, (int)max_calls, (int)frame_cap,
+                       ctx->s.sep_freq == 0 ? 1 : 0, d_bytes, d_lens, d_start, d_end, d_reason, d_n_calls);
+    return wn_launch_check("slice_kernel");
+}

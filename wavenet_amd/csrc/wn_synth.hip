@@ -1,0 +1,307 @@
+// K1: batched tone synthesis, and the synthetic channel's noise.
+//
+// Replaces transmite_freq / transmitir_silencio / emitir_trama (c1_shared.py:386-434),
+// the WAV variant guardar_trama_como_wav (c1_shared.py:440-471) and capa1's
+// transmite_freq / emitir_trama / WAV block (capa1.py:33-46, 163-173).
+//
+// Every tone restarts at t = 0 and every frequency is a whole number of Hz, so sample i
+// of a tone of f Hz is amp*sin(2*pi*((f*i) mod sr)/sr): an exact table lookup in one
+// quarter period of sr entries (built on the host in float64, so each output sample is
+// the correctly rounded value).  The kernel is HBM-write-bound: 4 bytes (float) or
+// 2 bytes (int16) per sample out, nothing but the ~1.5 KB segment table per frame in.
+//
+// Layout: one workgroup owns a contiguous part of one frame's samples.  It keeps the
+// quarter-wave table (sr/4+1 entries) and the frame's segment table in LDS, finds its
+// first segment once, and then every thread writes 4 consecutive samples per step.
+#include "wn_common.h"
+
+#define SYN_BLOCK 512
+#define SYN_MAX_SEGS 768  // segments of one frame the LDS table holds (2*274+4 fits)
+
+// ---------------------------------------------------------------------------------------
+// Segment layout: one thread per frame walks its bytes (<= 274) once.
+// ---------------------------------------------------------------------------------------
+__global__ void synth_layout_kernel(wn_scheme s, const uint8_t *__restrict__ frames,
+                                    const int32_t *__restrict__ lens, int stride, long long n, int variant,
+                                    int seg_cap, int32_t *__restrict__ seg_start, uint16_t *__restrict__ seg_freq,
+                                    int32_t *__restrict__ n_segs, long long *__restrict__ n_samples) {
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const uint8_t *fr = frames + f * (long long)stride;
+    int len = lens[f];
+    len = len < 0 ? 0 : (len > stride ? stride : len);
+    int32_t *st = seg_start + f * (long long)(seg_cap + 1);
+    uint16_t *fq = seg_freq + f * (long long)seg_cap;
+    int j = 0;
+    int32_t t = 0;
+#define PUSH(freq, cnt)                  \
+    do {                                 \
+        if (j < seg_cap) {               \
+            st[j] = t;                   \
+            fq[j] = (uint16_t)(freq);    \
+            ++j;                         \
+            t += (cnt);                  \
+        }                                \
+    } while (0)
+    if (s.sep_freq == 0) {  // prototype scheme (capa1.py:40-46; its WAV block has no end tone)
+        for (int i = 0; i < len; ++i) PUSH(s.base_freq + fr[i] * s.freq_step, s.tone_n);
+        if (variant == WN_EMIT_LIVE) PUSH(s.eof_freq, s.eof_n);
+    } else if (variant == WN_EMIT_LIVE) {  // c1_shared.py:420-433
+        PUSH(s.ping_freq, s.ping_n);
+        int prev = -1;
+        for (int i = 0; i < len; ++i) {
+            const int b = fr[i];
+            PUSH(s.sep_freq, b == prev ? s.sep_short_n : s.sep_n);
+            PUSH(s.base_freq + b * s.freq_step, s.tone_n);
+            prev = b;
+        }
+        PUSH(s.sep_freq, s.sep_n);
+        PUSH(s.eof_freq, s.eof_n);
+    } else {  // c1_shared.py:445-466
+        PUSH(s.ping_freq, s.sep_n);
+        PUSH(s.sep_freq, s.sep_n);
+        for (int i = 0; i < len; ++i) {
+            PUSH(s.base_freq + fr[i] * s.freq_step, s.tone_n);
+            PUSH(s.sep_freq, s.sep_n);
+        }
+        PUSH(s.eof_freq, s.tone_n);
+        PUSH(s.sep_freq, s.sep_n);
+    }
+#undef PUSH
+    st[j] = t;
+    n_segs[f] = j;
+    n_samples[f] = t;
+}
+
+// ---------------------------------------------------------------------------------------
+// Synthesis
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+    typedef float4 type;
+};
+template <>
+struct Vec4<int16_t> {
+    typedef short4 type;
+};
+
+// (f*d) mod sr for f, d < 2^15 (product < 2^30), sr a run-time constant.
+__device__ __forceinline__ int mod_sr(unsigned x, int sr, float inv_sr) {
+    int q = (int)((float)x * inv_sr);
+    int r = (int)x - q * sr;
+    r = r < 0 ? r + sr : r;
+    r = r >= sr ? r - sr : r;
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T sine_lookup(const T *tab, int m, int quarter) {
+    const int half = 2 * quarter;
+    const bool neg = m >= half;
+    const int m2 = neg ? m - half : m;
+    const int idx = m2 > quarter ? half - m2 : m2;
+    const T v = tab[idx];
+    return neg ? (T)(-v) : v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(const int32_t *__restrict__ seg_start,
+                                                          const uint16_t *__restrict__ seg_freq,
+                                                          const int32_t *__restrict__ n_segs, int seg_cap,
+                                                          long long n_frames, int parts, long long part_len,
+                                                          const long long *__restrict__ dst_off,
+                                                          const long long *__restrict__ fill_to,
+                                                          T *__restrict__ audio, long long audio_len,
+                                                          const T *__restrict__ g_tab, int quarter) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int32_t *s_start = (int32_t *)smem;                                   // SYN_MAX_SEGS+1
+    uint16_t *s_freq = (uint16_t *)(smem + (SYN_MAX_SEGS + 1) * 4);       // SYN_MAX_SEGS
+    T *tab = (T *)(smem + (SYN_MAX_SEGS + 1) * 4 + SYN_MAX_SEGS * 2 + 8); // quarter+1, 4-byte aligned
+    for (int i = threadIdx.x; i <= quarter; i += SYN_BLOCK) tab[i] = g_tab[i];
+    const int sr = 4 * quarter;
+    const float inv_sr = 1.0f / (float)sr;
+    typedef typename Vec4<T>::type V4;
+
+    const long long n_items = n_frames * parts;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const long long f = item / parts;
+        const int part = (int)(item - f * parts);
+        __syncthreads();  // table ready / previous item's segment table no longer read
+        const int ns = n_segs[f];
+        for (int i = threadIdx.x; i <= ns; i += SYN_BLOCK) s_start[i] = seg_start[f * (long long)(seg_cap + 1) + i];
+        for (int i = threadIdx.x; i < ns; i += SYN_BLOCK) s_freq[i] = seg_freq[f * (long long)seg_cap + i];
+        __syncthreads();
+        const int total = s_start[ns];
+        long long end = fill_to ? fill_to[f] : (long long)total;
+        if (end < total) end = total;
+        const long long base = dst_off[f];
+        if (base < 0) continue;                              // never write outside the buffer
+        if (base + end > audio_len) end = audio_len - base;
+        const long long p0 = (long long)part * part_len;
+        long long p1 = p0 + part_len;
+        if (p1 > end) p1 = end;
+        if (p0 >= p1) continue;
+        const bool vec_ok = (((base + p0) & 3) == 0) && ((part_len & 3) == 0);
+
+        // first segment of this part: binary search (same result in every thread)
+        int seg = 0;
+        if (p0 < total) {
+            int lo = 0, hi = ns - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if ((long long)s_start[mid] <= p0) lo = mid; else hi = mid - 1;
+            }
+            seg = lo;
+        } else {
+            seg = ns;
+        }
+        for (long long p = p0 + 4 * (long long)threadIdx.x; p < p1; p += 4 * SYN_BLOCK) {
+            while (seg < ns && p >= s_start[seg + 1]) ++seg;
+            T v[4];
+            int sg = seg;
+            int m = 0, fq = 0;
+            bool fresh = true;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long long pe = p + e;
+                if (pe >= total) {
+                    v[e] = (T)0;
+                    continue;
+                }
+                while (pe >= s_start[sg + 1]) {
+                    ++sg;
+                    fresh = true;
+                }
+                if (fresh) {
+                    fq = s_freq[sg];
+                    m = mod_sr((unsigned)fq * (unsigned)(pe - s_start[sg]), sr, inv_sr);
+                    fresh = false;
+                } else {
+                    m += fq;
+                    m = m >= sr ? m - sr : m;
+                }
+                v[e] = sine_lookup(tab, m, quarter);
+            }
+            T *dst = audio + base + p;
+            if (vec_ok && p + 4 <= p1) {
+                V4 o;
+                o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+                *(V4 *)dst = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (p + e < p1) dst[e] = v[e];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Channel noise: sample i gets sigma * z(seed, i), z from splitmix64 bits by Box-Muller.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void awgn_kernel(float *__restrict__ audio, long long n, float sigma,
+                                                   unsigned long long seed) {
+    // one thread makes two normals (samples 2i, 2i+1) from one 64-bit draw
+    const long long pairs = (n + 1) / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs;
+         i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long r = splitmix64(seed ^ splitmix64((unsigned long long)i));
+        const float u1 = ((float)(unsigned)(r >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+        const float u2 = (float)(unsigned)((r >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+        const float rad = sigma * sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        audio[2 * i] += rad * cs;
+        if (2 * i + 1 < n) audio[2 * i + 1] += rad * sn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" int wn_synth_layout(wn_ctx *ctx, const uint8_t *d_frames, const int32_t *d_lens, int32_t stride,
+                               int64_t n, int32_t variant, int32_t seg_cap, int32_t *d_seg_start,
+                               uint16_t *d_seg_freq, int32_t *d_n_segs, int64_t *d_n_samples, void *stream) {
+    WN_REQUIRE(ctx && n >= 0 && stride > 0, "ctx / n >= 0 / stride > 0");
+    WN_REQUIRE(variant == WN_EMIT_LIVE || variant == WN_EMIT_WAV, "variant");
+    WN_REQUIRE(seg_cap >= 2 * stride + 4 && seg_cap <= SYN_MAX_SEGS, "2*stride+4 <= seg_cap <= 768");
+    WN_REQUIRE(n == 0 || (d_frames && d_lens && d_seg_start && d_seg_freq && d_n_segs && d_n_samples),
+               "null device pointer");
+    if (n == 0) return WN_OK;
+    const unsigned blocks = (unsigned)((n + 127) / 128);
+    hipLaunchKernelGGL(synth_layout_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ctx->s, d_frames,
+                       d_lens, (int)stride, (long long)n, (int)variant, (int)seg_cap, d_seg_start, d_seg_freq,
+                       d_n_segs, (long long *)d_n_samples);
+    return wn_launch_check("synth_layout_kernel");
+}
+
+extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uint16_t *d_seg_freq,
+                              const int32_t *d_n_segs, int32_t seg_cap, int64_t n, const int64_t *d_dst_off,
+                              const int64_t *d_fill_to, int64_t slot_len, void *d_audio, int64_t audio_len,
+                              int32_t fmt, void *stream) {
+    WN_REQUIRE(ctx && n >= 0, "ctx / n >= 0");
+    WN_REQUIRE(fmt == WN_FMT_F32 || fmt == WN_FMT_I16, "fmt");
+    WN_REQUIRE(seg_cap > 0 && seg_cap <= SYN_MAX_SEGS, "0 < seg_cap <= 768");
+    WN_REQUIRE(slot_len > 0 && slot_len < (1ll << 31) && audio_len > 0, "0 < slot_len < 2^31 / audio_len > 0");
+    WN_REQUIRE(n == 0 || (d_seg_start && d_seg_freq && d_n_segs && d_dst_off && d_audio), "null device pointer");
+    if (n == 0) return WN_OK;
+    // enough workgroups to fill the chip: split frames into parts of >= 8192 samples
+    const long long want = (long long)ctx->num_cus * 8;
+    long long parts = (want + n - 1) / n;
+    const long long max_parts = (slot_len + 8191) / 8192;
+    if (parts > max_parts) parts = max_parts;
+    if (parts < 1) parts = 1;
+    long long part_len = (slot_len + parts - 1) / parts;
+    part_len = (part_len + 3) & ~3ll;
+    parts = (slot_len + part_len - 1) / part_len;
+    long long items = n * parts;
+    long long blocks = items < want ? items : want;
+    const size_t esz = fmt == WN_FMT_F32 ? 4 : 2;
+    const size_t lds = (SYN_MAX_SEGS + 1) * 4 + SYN_MAX_SEGS * 2 + 8 + (size_t)(ctx->quarter + 1) * esz;
+    WN_REQUIRE(lds <= 150 * 1024, "sample_rate too large for the LDS sine table");
+    hipStream_t st = (hipStream_t)stream;
+    if (fmt == WN_FMT_F32) {
+        static size_t attr = 0;
+        if (lds > attr) {
+            WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<float>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = lds;
+        }
+        hipLaunchKernelGGL(synth_kernel<float>, dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,
+                           d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, part_len,
+                           (const long long *)d_dst_off, (const long long *)d_fill_to, (float *)d_audio,
+                           (long long)audio_len, (const float *)ctx->d_sin_f32, ctx->quarter);
+    } else {
+        static size_t attr = 0;
+        if (lds > attr) {
+            WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<int16_t>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = lds;
+        }
+        hipLaunchKernelGGL(synth_kernel<int16_t>, dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,
+                           d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, part_len,
+                           (const long long *)d_dst_off, (const long long *)d_fill_to, (int16_t *)d_audio,
+                           (long long)audio_len, (const int16_t *)ctx->d_sin_i16, ctx->quarter);
+    }
+    return wn_launch_check("synth_kernel");
+}
+
+extern "C" int wn_channel_awgn(wn_ctx *ctx, float *d_audio, int64_t n, float sigma, uint64_t seed, void *stream) {
+    WN_REQUIRE(ctx && n >= 0 && sigma >= 0.0f, "ctx / n >= 0 / sigma >= 0");
+    WN_REQUIRE(n == 0 || d_audio, "null device pointer");
+    if (n == 0 || sigma == 0.0f) return WN_OK;
+    const long long pairs = (n + 1) / 2;
+    long long blocks = (pairs + 255) / 256;
+    const long long cap = (long long)ctx->num_cus * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(awgn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_audio,
+                       (long long)n, sigma, (unsigned long long)seed);
+    return wn_launch_check("awgn_kernel");
+}
