@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own copy of the HIP runtime.  Device pointers and streams handed to the
+# library come from torch, so the library must bind to that same runtime instance: load
+# torch first, then libwavenet_hip.so resolves libamdhip64 to the copy already mapped.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwavenet_hip.so")
 
