@@ -1,0 +1,362 @@
+"""The reference's layer-1 function surface (DispositivoWaveNET/dispositivo_wavenet/
+c1_shared.py) over the HIP kernels and a synthetic audio device.
+
+Same names, arguments, return values and error behaviour as the reference; every
+checksum, frame, tone and detection goes through libwavenet_hip.so (one-element batches
+here; `wavenet_amd.modem.Modem` is the batched form of the same calls).  There is no CPU
+path: without a GPU the first call that needs the modem raises.
+
+The sound card (sounddevice.play/rec) and the wall clock are replaced by a
+`CanalSintetico`; install one with `usar_canal()`.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import modem as M
+from .canal import CanalSintetico
+
+# ------------------------------------------------------------------------------------------
+# Constants (reference c1_shared.py:15-44)
+# ------------------------------------------------------------------------------------------
+SAMPLE_RATE = 44100
+BYTE_DURATION = 0.24
+SILENCE_DURATION = 0.30
+BASE_FREQ = 350
+SILENCE_FREQ = 200
+FREQ_STEP = 70
+
+TIPO_PING = 0x01
+TIPO_TRAMA_ARCHIVO_INFO = 0x02
+TIPO_TRAMA_ARCHIVO = 0x03
+TIPO_TRAMA_FINAL_ARCHIVO = 0x04
+TIPO_ERROR = 0x05
+TIPO_OK = 0x06
+
+VERSION = 1
+
+TIME_TO_SAY_OK = 10
+TIMES_TO_COMUNICATE_OK = 3
+TIME_TO_SAY_128_BYTES = 113
+TIMES_TO_COMUNICATE_128_BYTES = 3
+
+PING_FREQ = 250
+FREQ_EOF = 300
+
+_MENSAJES = {
+    L.ST_EMPTY: "Faltan argumentos para crear la trama",
+    L.ST_SHORT_HEADER: "Trama muy corta",
+    L.ST_SHORT_BODY: "La trama no contiene suficiente longitud según el campo 'length'",
+}
+
+# ------------------------------------------------------------------------------------------
+# Device state: one modem per scheme, one current channel
+# ------------------------------------------------------------------------------------------
+_modems: dict = {}
+_canal: CanalSintetico | None = None
+
+
+def modem(esquema: str = "B") -> M.Modem:
+    if esquema not in _modems:
+        _modems[esquema] = M.Modem(M.esquema_b() if esquema == "B" else M.esquema_a())
+    return _modems[esquema]
+
+
+def usar_canal(canal: CanalSintetico | None) -> CanalSintetico | None:
+    """Install the synthetic audio device every play/rec of this module goes to."""
+    global _canal
+    previo, _canal = _canal, canal
+    return previo
+
+
+def canal() -> CanalSintetico:
+    global _canal
+    if _canal is None:
+        _canal = CanalSintetico(M.esquema_b())
+    return _canal
+
+
+def _dev(data: bytes, ancho: int) -> torch.Tensor:
+    fila = np.zeros((1, ancho), dtype=np.uint8)
+    fila[0, :len(data)] = np.frombuffer(bytes(data), dtype=np.uint8)
+    return torch.from_numpy(fila).to(modem().device)
+
+
+def _ancho(n: int) -> int:
+    return max(16, (n + 15) & ~15)
+
+
+# ------------------------------------------------------------------------------------------
+# Frames (reference c1_shared.py:57-143)
+# ------------------------------------------------------------------------------------------
+class Trama:
+    """[versión][MAC_org][MAC_dest][tipo][longitud][payload][checksum]"""
+
+    def __init__(self, bytes_trama=None, version=None, mac_origen=None, mac_destino=None, tipo=None, payload=None):
+        if bytes_trama:
+            self.bytes_trama = bytearray(bytes_trama)
+            self._parse()
+        else:
+            if None in (version, mac_origen, mac_destino, tipo, payload):
+                raise ValueError(_MENSAJES[L.ST_EMPTY])
+            self.version = version
+            self.mac_origen = mac_origen
+            self.mac_destino = mac_destino
+            self.tipo = tipo
+            self.payload = payload
+            self.length = len(payload)
+            self._build()
+
+    def _parse(self):
+        raw = bytes(self.bytes_trama)
+        m = modem()
+        rec = M.Modem.records_to_numpy(
+            m.parse_frames(_dev(raw, _ancho(len(raw))), torch.tensor([len(raw)], dtype=torch.int32, device=m.device)))[0]
+        if rec["status"] != L.ST_OK:
+            raise ValueError(_MENSAJES[int(rec["status"])])
+        self.version = self.bytes_trama[0]
+        self.mac_origen = self.bytes_trama[1:7]
+        self.mac_destino = self.bytes_trama[7:13]
+        self.tipo = int(rec["tipo"])
+        self.length = int(rec["length"])
+        self.payload = self.bytes_trama[15:15 + self.length]
+        self.checksum = self.bytes_trama[15 + self.length:15 + self.length + 4]
+        self._crc_ok = bool(rec["crc_ok"])
+
+    def _build(self):
+        if not (0 <= self.version <= 255 and 0 <= self.tipo <= 255 and self.length <= 255):
+            raise ValueError("byte must be in range(0, 256)")
+        if len(self.mac_origen) != 6 or len(self.mac_destino) != 6:
+            raise ValueError("las direcciones MAC deben tener 6 bytes")
+        m = modem()
+        campos = bytes([self.version]) + bytes(self.mac_origen) + bytes(self.mac_destino) + \
+            bytes([self.tipo, self.length, 0])
+        frames, lens = m.build_frames(_dev(campos, 16), _dev(bytes(self.payload), _ancho(self.length)), 288)
+        n = int(lens[0])
+        self.bytes_trama = bytearray(frames[0, :n].cpu().numpy().tobytes())
+        self.checksum = self.bytes_trama[n - 4:n]
+
+    def get_bytes(self):
+        return bytes(self.bytes_trama)
+
+    def get_checksum_valido(self):
+        header_y_payload = self.bytes_trama[:15 + self.length]
+        return self.checksum == calcular_checksum(header_y_payload)
+
+    def imprimir(self):
+        def mac_to_str(mac_bytes):
+            return ':'.join(f'{b:02x}' for b in mac_bytes)
+
+        logging.info("----- TRAMA -----")
+        logging.info(f"Versión     : {self.version}")
+        logging.info(f"MAC Origen  : {mac_to_str(self.mac_origen)}")
+        logging.info(f"MAC Destino : {mac_to_str(self.mac_destino)}")
+        logging.info(f"Tipo        : {self.tipo}")
+        logging.info(f"Longitud    : {self.length}")
+        logging.info(f"Payload     : {self.payload}")
+        logging.info(f"Checksum    : {self.checksum.hex()}")
+        logging.info(f"Checksum válido: {self.get_checksum_valido()}")
+        logging.info("-----------------")
+
+
+def byte_to_freq(byte):
+    return BASE_FREQ + byte * FREQ_STEP
+
+
+def freq_to_byte(freq):
+    """Byte of a frequency, or None when it is not within half a step of a tone
+    (reference c1_shared.py:152-163).  Scalar host arithmetic; the kernels apply the same
+    rule per FFT bin through their class table."""
+    candidato = int(round((freq - BASE_FREQ) / FREQ_STEP))
+    cerca = abs(freq - (BASE_FREQ + candidato * FREQ_STEP)) < (FREQ_STEP / 2)
+    return candidato if (0 <= candidato <= 255 and cerca) else None
+
+
+def mac_str_to_bytes(mac_str):
+    try:
+        parts = mac_str.split(":")
+        if len(parts) != 6:
+            raise ValueError
+        return bytes(int(part, 16) for part in parts)
+    except Exception:
+        raise argparse.ArgumentTypeError(f"MAC inválida: {mac_str}")
+
+
+def calcular_checksum(trama):
+    """CRC-32 of `trama`, 4 bytes big-endian (reference c1_shared.py:178-187)."""
+    data = bytes(trama)
+    m = modem()
+    crc = m.crc32(_dev(data, _ancho(len(data))), torch.tensor([len(data)], dtype=torch.int32, device=m.device))
+    return int(crc[0]).to_bytes(4, byteorder='big')
+
+
+def crear_trama(version, bytes_mac_org, bytes_mac_dest, tipo, cur_payload):
+    return Trama(version=version, mac_origen=bytes_mac_org, mac_destino=bytes_mac_dest, tipo=tipo,
+                 payload=cur_payload)
+
+
+def crear_trama_archivo_info(bytes_mac_org, bytes_mac_dest, cantidad_tramas, nombre_archivo):
+    payload = cantidad_tramas.to_bytes(4, byteorder='big') + nombre_archivo.encode('utf-8')
+    return crear_trama(VERSION, bytes_mac_org, bytes_mac_dest, TIPO_TRAMA_ARCHIVO_INFO, payload)
+
+
+def decodificar_payload_archivo_info(payload: bytes):
+    return int.from_bytes(payload[:4], byteorder='big'), bytes(payload[4:]).decode('utf-8')
+
+
+def verificar_datos_esperados(trama: Trama, tipo_esperado, org_esperado, dst_esperado):
+    return bool(trama.tipo == tipo_esperado and trama.mac_origen == org_esperado
+                and trama.mac_destino == dst_esperado)
+
+
+def crear_trama_ok(bytes_mac_org, bytes_mac_dest, bytes_checksum_received):
+    return crear_trama(VERSION, bytes_mac_org, bytes_mac_dest, TIPO_OK, bytes_checksum_received)
+
+
+# ------------------------------------------------------------------------------------------
+# Sound (reference c1_shared.py:286-434)
+# ------------------------------------------------------------------------------------------
+def detectar_frecuencia(audio, sample_rate):
+    """Dominant frequency of one receive window (reference c1_shared.py:286-299).  The
+    window must have the length the kernels are built for (7055 or 2205 samples)."""
+    x = torch.as_tensor(np.asarray(audio) if not torch.is_tensor(audio) else audio).reshape(-1)
+    n = x.numel()
+    esquema = {7055: "B", 2205: "A"}.get(n)
+    if esquema is None or sample_rate != SAMPLE_RATE:
+        raise ValueError(f"detectar_frecuencia: ventana de {n} muestras a {sample_rate} Hz no soportada")
+    m = modem(esquema)
+    buf = torch.zeros(M.pad4(n), dtype=torch.float32, device=m.device)
+    buf[:n] = x.to(m.device, torch.float32)
+    _, _, kbin = m.detect(buf, 1, buf.numel(), 1)
+    return abs(int(kbin[0, 0]) * (1.0 / (n * (1 / sample_rate))))     # fftfreq(n, 1/sr)[k]
+
+
+def _ventanas_disponibles(c: CanalSintetico, cuantas: int):
+    n = c.esquema.win_n
+    c.reservar(c.leido + cuantas * n + 4)
+    return c.audio, c.leido, cuantas
+
+
+def escuchar_y_retornar_trama(timeout):
+    """Listens for one frame for `timeout` seconds of channel time; the clock restarts at
+    the ping (reference c1_shared.py:301-355).  Returns the Trama or raises ValueError."""
+    c, m = canal(), modem()
+    tw = m.timeout_windows(timeout)
+    audio, desde, nwin = _ventanas_disponibles(c, 2 * tw)
+    cls, _, _ = m.detect(audio, 1, audio.numel(), nwin, desde)
+    by, lens, _, end, _, _ = m.slice(cls, tw, 1, 288)
+    usados = int(end[0, 0])
+    c.leido += usados * c.esquema.win_n
+    recibidos = by[0, 0, :int(lens[0, 0])].cpu().numpy().tolist()
+    logging.info(f"{recibidos}")
+    return Trama(bytes_trama=recibidos)
+
+
+def escuchar_ping(timeout):
+    """True if a ping tone dominates some window within `timeout` seconds
+    (reference c1_shared.py:357-384)."""
+    c, m = canal(), modem()
+    tw = m.timeout_windows(timeout)
+    audio, desde, nwin = _ventanas_disponibles(c, tw)
+    _, _, verdict = m.sync_scan(audio, 1, audio.numel(), nwin, desde)
+    v = verdict[0].cpu().numpy()
+    if (v == 2).any():       # undecided windows: only the spectrum can tell
+        cls, _, _ = m.detect(audio, 1, audio.numel(), nwin, desde)
+        es_ping = (cls[0].cpu().numpy().astype(np.uint16) & L.CLS_PING) != 0
+    else:
+        es_ping = v == 1
+    idx = np.flatnonzero(es_ping)
+    if len(idx):
+        c.leido += (int(idx[0]) + 1) * c.esquema.win_n
+        logging.info("Escuche el ping")
+        return True
+    c.leido += nwin * c.esquema.win_n
+    logging.info("Timeout alcanzado. Terminando escucha.")
+    return False
+
+
+def _tono(freq, n):
+    """Appends n samples of a `freq` Hz tone to the channel (one-segment schedule)."""
+    c, m = canal(), modem()
+    dev = m.device
+    lay = (torch.tensor([[0, n]], dtype=torch.int32, device=dev), torch.tensor([[freq]], dtype=torch.int16, device=dev),
+           torch.tensor([1], dtype=torch.int32, device=dev), None)
+    pos = c.posicion_escritura()
+    c.reservar(pos + n)
+    m.synth(lay, torch.tensor([pos], dtype=torch.int64, device=dev), c.audio, M.pad4(n))
+    c.avanzar_escritura(n)
+
+
+def transmite_freq(freq, duration=BYTE_DURATION):
+    _tono(int(freq), int(SAMPLE_RATE * duration))
+
+
+def transmitir_silencio(freq=SILENCE_FREQ, duration=SILENCE_DURATION):
+    _tono(int(freq), int(SAMPLE_RATE * duration))
+
+
+def ejecutar_ping():
+    canal().sleep(2)
+    transmite_freq(PING_FREQ, duration=BYTE_DURATION * 2)
+
+
+def emitir_trama(trama):
+    """Puts one frame on the channel: ping, separator + tone per byte, separator, EOF
+    (reference c1_shared.py:415-434)."""
+    c, m = canal(), modem()
+    raw = bytes(trama.bytes_trama)
+    frames = _dev(raw, _ancho(len(raw)))
+    lens = torch.tensor([len(raw)], dtype=torch.int32, device=m.device)
+    lay = m.layout(frames, lens, L.EMIT_LIVE)
+    n = M.host_frame_samples(m.esquema, raw, L.EMIT_LIVE)
+    pos = c.posicion_escritura()
+    c.reservar(pos + n)
+    m.synth(lay, torch.tensor([pos], dtype=torch.int64, device=m.device), c.audio, M.pad4(n))
+    c.avanzar_escritura(n)
+    logging.info("Trama transmitida.")
+
+
+# ------------------------------------------------------------------------------------------
+# Files (reference c1_shared.py:440-525)
+# ------------------------------------------------------------------------------------------
+def trama_a_int16(trama) -> np.ndarray:
+    """The samples guardar_trama_como_wav writes (reference c1_shared.py:445-467)."""
+    m = modem()
+    raw = bytes(trama.bytes_trama)
+    n = M.host_frame_samples(m.esquema, raw, L.EMIT_WAV)
+    audio, _ = m.encode_streams(_dev(raw, _ancho(len(raw))), torch.tensor([len(raw)], dtype=torch.int32, device=m.device),
+                                M.pad4(n), variant=L.EMIT_WAV, dtype=torch.int16)
+    return audio[0, :n].cpu().numpy()
+
+
+def guardar_trama_como_wav(trama, nombre_archivo):
+    from scipy.io.wavfile import write
+    write(nombre_archivo, SAMPLE_RATE, trama_a_int16(trama))
+    trama.imprimir()
+    logging.info(f"Trama guardada como archivo WAV: {nombre_archivo}")
+
+
+def _tramas_desde_bytes(data: bytes, mac_origen_str, mac_destino_str):
+    org, dst = mac_str_to_bytes(mac_origen_str), mac_str_to_bytes(mac_destino_str)
+    return [crear_trama(VERSION, org, dst, TIPO_TRAMA_ARCHIVO, data[i:i + 107]) for i in range(0, len(data), 107)]
+
+
+def obtener_tramas_desde_archivo(file_path, mac_origen_str, mac_destino_str):
+    with open(file_path, 'rb') as f:
+        return _tramas_desde_bytes(f.read(), mac_origen_str, mac_destino_str)
+
+
+def obtener_tramas_desde_string(string, mac_origen_str, mac_destino_str):
+    if isinstance(string, str):
+        string = string.encode()
+    return _tramas_desde_bytes(string, mac_origen_str, mac_destino_str)
+
+
+def guardar_archivo_en_tramas_wav(nombre_archivo, mac_org_str, mac_dest_str):
+    for i, trama in enumerate(obtener_tramas_desde_archivo(nombre_archivo, mac_org_str, mac_dest_str)):
+        guardar_trama_como_wav(trama, f"{nombre_archivo}_trama_{i+1}.wav")
