@@ -107,7 +107,7 @@ int64_t wn_host_frame_samples(const wn_scheme *s, const uint8_t *frame, int32_t 
 int wn_scheme_init(const wn_scheme *s, wn_ctx **out);
 int wn_ctx_destroy(wn_ctx *ctx);
 /* Relative band under which the two largest bins of a window are re-evaluated in
- * float64 (default 3e-5).  Tests raise it to force that path. */
+ * float64 (default 5e-5).  Tests raise it to force that path. */
 int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
 /* Counters since the last call (synchronises `stream`): out[0] windows detected,
  * out[1] windows whose top two bins were re-evaluated in float64, out[2] windows whose

@@ -25,7 +25,7 @@
 
 struct SyncBins {
     int n_ping;               // bins [0, n_ping) are the ping bins
-    int n_used;               // bins [n_ping, n_used) are rivals; slot SYNC_NB-1 = excluded bin
+    int n_used;               // bins [n_ping, n_used) are rivals; slot n_used = excluded bin
     int bin[SYNC_NB];
     float2 step[SYNC_NB];     // rotation by 256 samples
     float2 rot[SYNC_NB][4];   // rotation by q = 0..3 samples
@@ -39,6 +39,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
+template <int NB>
 __global__ __launch_bounds__(256) void sync_kernel(const float *__restrict__ audio, long long audio_len,
                                                    long long n_streams, long long stream_stride,
                                                    long long first_sample, long long n_windows, int N,
@@ -53,51 +54,60 @@ __global__ __launch_bounds__(256) void sync_kernel(const float *__restrict__ aud
         const long long a0 = g0 & ~3ll;
         const int off = (int)(g0 - a0);
         // twiddle of this lane's first float4: sample index n0 = 4*lane - off (may be < 0)
-        float2 tw[SYNC_NB];
+        float2 tw[NB];
 #pragma unroll
-        for (int b = 0; b < SYNC_NB; ++b) {
+        for (int b = 0; b < NB; ++b) {
             int m = (int)(((long long)sb.bin[b] * (4 * lane - off)) % N);
             m = m < 0 ? m + N : m;
             float sn, cs;
             sincospif((float)m * sb.inv_n2, &sn, &cs);
             tw[b] = make_float2(cs, sn);
         }
-        float are[SYNC_NB][4], aim[SYNC_NB][4];
+        float are[NB][4], aim[NB][4];
 #pragma unroll
-        for (int b = 0; b < SYNC_NB; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int q = 0; q < 4; ++q) are[b][q] = aim[b][q] = 0.f;
         float sx = 0.f, sxx = 0.f;
         const int nv = (N + off + 3) / 4;  // float4s covering the window
-        for (int j = lane; j < nv; j += 64) {
-            const int e = 4 * j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a0 + e + 4 <= audio_len) v = *(const float4 *)(audio + a0 + e);
-            const int n0 = e - off;
-            float x[4] = {v.x, v.y, v.z, v.w};
+        // four float4 loads in flight per lane before any arithmetic: the kernel is a pure
+        // stream and needs the bytes in flight to cover HBM latency
+        for (int j0 = lane; j0 < nv; j0 += 256) {
+            float4 vv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + q;
-                x[q] = (n >= 0 && n < N) ? x[q] : 0.f;
-                sx += x[q];
-                sxx = fmaf(x[q], x[q], sxx);
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * (j0 + 64 * u);
+                vv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + 64 * u < nv && a0 + e + 4 <= audio_len) vv[u] = *(const float4 *)(audio + a0 + e);
             }
 #pragma unroll
-            for (int b = 0; b < SYNC_NB; ++b) {
+            for (int u = 0; u < 4; ++u) {
+                const int n0 = 4 * (j0 + 64 * u) - off;
+                float x[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    are[b][q] = fmaf(x[q], tw[b].x, are[b][q]);
-                    aim[b][q] = fmaf(x[q], tw[b].y, aim[b][q]);
+                    const int n = n0 + q;
+                    x[q] = (n >= 0 && n < N) ? x[q] : 0.f;
+                    sx += x[q];
+                    sxx = fmaf(x[q], x[q], sxx);
                 }
-                const float c = tw[b].x * sb.step[b].x - tw[b].y * sb.step[b].y;
-                const float sn = tw[b].x * sb.step[b].y + tw[b].y * sb.step[b].x;
-                tw[b] = make_float2(c, sn);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        are[b][q] = fmaf(x[q], tw[b].x, are[b][q]);
+                        aim[b][q] = fmaf(x[q], tw[b].y, aim[b][q]);
+                    }
+                    const float c = tw[b].x * sb.step[b].x - tw[b].y * sb.step[b].y;
+                    const float sn = tw[b].x * sb.step[b].y + tw[b].y * sb.step[b].x;
+                    tw[b] = make_float2(c, sn);
+                }
             }
         }
         // apply the in-float4 offsets, reduce over the wave
-        float mag2[SYNC_NB];
+        float mag2[NB];
 #pragma unroll
-        for (int b = 0; b < SYNC_NB; ++b) {
+        for (int b = 0; b < NB; ++b) {
             float re = 0.f, im = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void sync_kernel(const float *__restrict__ aud
         if (lane == 0) {
             float pmax = 0.f, psum = 0.f, rival = sx * sx;
 #pragma unroll
-            for (int b = 0; b < SYNC_NB; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 if (b < sb.n_ping) {
                     pmax = fmaxf(pmax, mag2[b]);
                     psum += mag2[b];
@@ -122,9 +132,9 @@ __global__ __launch_bounds__(256) void sync_kernel(const float *__restrict__ aud
                     rival = fmaxf(rival, mag2[b]);
                 }
             }
-            float known = psum + mag2[SYNC_NB - 1];
+            float known = psum + mag2[NB - 1];
 #pragma unroll
-            for (int b = 0; b < SYNC_NB - 1; ++b)
+            for (int b = 0; b < NB - 1; ++b)
                 if (b >= sb.n_ping && b < sb.n_used) known += mag2[b];
             const float half = 0.5f * ((float)N * sxx - sx * sx);
             const float rest = fmaxf(half - known, 0.f);  // energy of the bins not computed
@@ -189,8 +199,8 @@ extern "C" int wn_sync_scan(wn_ctx *ctx, const float *d_audio, int64_t audio_len
         if (!dup) fill_rot(sb, slot++, k, N);
     }
     sb.n_used = slot;
-    for (; slot < SYNC_NB - 1; ++slot) fill_rot(sb, slot, sb.bin[0], N);  // idle slots repeat a ping bin
-    fill_rot(sb, SYNC_NB - 1, (N - 1) / 2, N);                            // the bin argmax never sees
+    const int nb = slot + 1;
+    fill_rot(sb, slot, (N - 1) / 2, N);  // last slot: the bin of [1, N/2] that argmax never sees
     sb.inv_n2 = (float)(2.0 / (double)N);
     // bins of [1, N/2) not computed: all but ping and rivals
     sb.others = (ctx->nbins - 1) - sb.n_used;
@@ -199,8 +209,19 @@ extern "C" int wn_sync_scan(wn_ctx *ctx, const float *d_audio, int64_t audio_len
     long long blocks = (total + 3) / 4;
     const long long cap = (long long)ctx->num_cus * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(sync_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_audio,
-                       (long long)audio_len, (long long)n_streams, (long long)stream_stride,
-                       (long long)first_sample, (long long)n_windows, N, sb, d_ping_energy, d_win_energy, d_verdict);
+#define SYNC_LAUNCH(NBV)                                                                                         \
+    hipLaunchKernelGGL(sync_kernel<NBV>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_audio,     \
+                       (long long)audio_len, (long long)n_streams, (long long)stream_stride,                     \
+                       (long long)first_sample, (long long)n_windows, N, sb, d_ping_energy, d_win_energy, d_verdict)
+    switch (nb) {
+        case 2: SYNC_LAUNCH(2); break;
+        case 3: SYNC_LAUNCH(3); break;
+        case 4: SYNC_LAUNCH(4); break;
+        case 5: SYNC_LAUNCH(5); break;
+        case 6: SYNC_LAUNCH(6); break;
+        case 7: SYNC_LAUNCH(7); break;
+        default: SYNC_LAUNCH(8); break;
+    }
+#undef SYNC_LAUNCH
     return wn_launch_check("sync_kernel");
 }
