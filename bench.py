@@ -31,10 +31,12 @@ WIN = 7055
 
 
 def detect_flop_per_window(n1: int, n2: int) -> float:
-    """Algorithmic flop of the prime-factor DFT of one window: stage 1 is a real
-    [n1 x n2] x [n2 x 2*k2] product, stage 2 a real [2*n1 x 2*n1] x [2*n1 x k2] one."""
-    k2 = n2 // 2 + 1
-    return 2.0 * n1 * n2 * (2 * k2) + 2.0 * (2 * n1) * (2 * n1) * k2
+    """Algorithmic flop of the folded prime-factor DFT of one window (multiply-adds of the
+    matrix products only, without tile padding).  Stage 1: for each of n1 rows, real and
+    imaginary part of h2+1 columns from h2+1 folded samples.  Stage 2: four real sums over
+    h1+1 folded rows for each of (h1+1) x (h2+1) outputs pairs."""
+    h1, h2 = n1 // 2 + 1, n2 // 2 + 1
+    return 2.0 * n1 * h2 * h2 * 2 + 2.0 * h1 * h2 * h1 * 4
 
 
 def make_inputs(n, first_index, device):

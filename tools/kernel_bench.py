@@ -88,7 +88,8 @@ def main():
             mean, best = timed(lambda: m.detect(audio, S, stride, nwin), args.reps)
             n1, n2 = M.host_dft_plan(m.esquema)
             k2 = n2 // 2 + 1
-            flop = (2.0 * n1 * n2 * 2 * k2 + 2.0 * (2 * n1) ** 2 * k2) * S * nwin
+            h1 = n1 // 2 + 1
+            flop = (2.0 * n1 * k2 * k2 * 2 + 2.0 * h1 * k2 * h1 * 4) * S * nwin
             out.append({"kernel": "detect_kernel<83,85>+refine", "bound": "mfma", "ms": mean, "ms_min": best,
                         "algorithmic_flop": flop, "achieved_TFLOPs": flop / mean / 1e9, "peak_TFLOPs": 157.3,
                         "frac": flop / mean / 1e9 / 157.3, "hbm_GBps": S * nwin * WIN * 4 / mean / 1e6,

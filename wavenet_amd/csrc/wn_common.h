@@ -17,7 +17,7 @@ struct wn_ctx {
     int32_t n, n1, n2, nbins;
     int32_t e1, e2;
     uint16_t *d_cls_lut;  // nbins class words
-    float4 *d_tw1;        // n1 entries (cos, cos-sin, cos+sin, sin)(2*pi*m/n1)
+    float2 *d_tw1;        // n1 entries (cos, sin)(2*pi*m/n1)
     float2 *d_tw2;        // n2 entries (cos, -sin)(2*pi*m/n2)
     double tie_band;
     unsigned long long *d_stats;  // 4 counters

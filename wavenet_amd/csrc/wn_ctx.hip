@@ -266,11 +266,11 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
             }
     }
     {
-        std::vector<float4> t1(n1);
+        std::vector<float2> t1(n1);
         std::vector<float2> t2(n2);
         for (int32_t m = 0; m < n1; ++m) {
             const double a = 2.0 * M_PI * (double)m / (double)n1;
-            t1[m] = make_float4((float)cos(a), (float)(cos(a) - sin(a)), (float)(cos(a) + sin(a)), (float)sin(a));
+            t1[m] = make_float2((float)cos(a), (float)sin(a));
         }
         for (int32_t m = 0; m < n2; ++m) {
             const double a = 2.0 * M_PI * (double)m / (double)n2;

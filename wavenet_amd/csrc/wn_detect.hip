@@ -5,29 +5,46 @@
 //
 // The whole spectrum is needed: in a noisy or mixed window the reference's argmax can
 // land on any bin, and almost every bin maps to some byte.  The window length N factors
-// into coprime n1*n2 (7055 = 83*85, 2205 = 45*49), so the N-point DFT is computed by the
-// prime-factor (Good-Thomas) algorithm, with no twiddles between its two stages:
+// into coprime odd n1*n2 (7055 = 83*85, 2205 = 45*49), so the N-point DFT is computed by
+// the prime-factor (Good-Thomas) algorithm, with no twiddles between its two stages:
 //
 //   x2[a][b] = x[(n2*a + n1*b) mod N]                         a < n1, b < n2
-//   Y[a][k2] = sum_b x2[a][b] * exp(-2*pi*i*b*k2/n2)          k2 <= n2/2 (real input)
+//   Y[a][k2] = sum_b x2[a][b] * exp(-2*pi*i*b*k2/n2)          k2 <= h2 = n2/2 (real input)
 //   Z[k1][k2] = sum_a exp(-2*pi*i*a*k1/n1) * Y[a][k2]
-//   X[k] = Z[k mod n1][k mod n2]; bins with (k mod n2) > n2/2 are mirrors of these.
+//   X[k] = Z[k mod n1][k mod n2]; bins with (k mod n2) > h2 are mirrors of these.
 //
-// Both stages are small dense contractions and run on the matrix cores in f32
-// (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation), 3.6 MFLOP per window
-// instead of the 99.5 MFLOP of a dense N x N/2 DFT.  The stage-1 result tile is already
-// laid out as the B operand of stage 2 (rows on register index and lane group), so Y
-// never leaves the registers.
+// Both stages fold their summation index in mirrored pairs (cos is even, sin is odd in the
+// index), which halves the multiplications, and stage 2 also produces rows k1 and n1-k1
+// from the same four real sums:
+//
+//   stage 1, b' in [0, h2]:  Yr = sum cos(b'k2) (x2[a][b'] + x2[a][n2-b']),
+//                            Yi = -sum sin(b'k2) (x2[a][b'] - x2[a][n2-b'])
+//   stage 2, a' in [0, h1], k1 in [0, h1], with S = Y[a'] + Y[n1-a'], D = Y[a'] - Y[n1-a']:
+//       A = sum cos(a'k1) Sr, B = sum sin(a'k1) Di, C = sum cos(a'k1) Si, E = sum sin(a'k1) Dr
+//       Z[k1] = (A + B) + i(C - E),   Z[n1-k1] = (A - B) + i(C + E)
+//
+// All sums are small dense contractions and run on the matrix cores in f32
+// (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation): 792 instructions of
+// 2048 FLOP per 7055-sample window (1.2 MFLOP useful) instead of the 99.5 MFLOP of a dense
+// N x N/2 DFT.  A stage-1 result tile is already laid out as the B operand of stage 2
+// (rows on register index and lane group); the mirrored rows n1-a' are computed as separate
+// row tiles with the same lane/register positions, so S and D are plain register adds and
+// Y never leaves the registers.
 //
 // One wave owns one window at a time; a workgroup is four independent waves (one per
-// SIMD, the whole 512-entry register file each).  The window is staged in LDS because
-// the prime-factor index map is a gather; the next window is fetched from HBM into
-// registers while stage 2 runs.  Bound: matrix cores (f32 MFMA, 64 FLOP/clk/SIMD).
+// SIMD, the whole 512-entry register file each).  The window is staged in LDS by DMA
+// because the prime-factor index map is a gather; the next window is fetched while stage 2
+// runs.  With one wave per SIMD every instruction costs an issue slot, so the address
+// arithmetic, LDS reads and the arg-max epilogue are dealt out in fixed shares between the
+// MFMAs (compile-time generated slots) to issue in their shadow.
+// Bound: matrix cores (f32 MFMA, 64 FLOP/clk/SIMD).
 //
-// Decisions must equal the reference's float64 FFT.  Windows whose two largest bins are
-// closer than a relative band (default 5e-5, ~10x the f32 error) are re-evaluated for
-// those bins in float64 by direct summation with exactly reduced phases; if a third bin
-// is in the band too, the whole spectrum is.
+// Decisions must equal the reference's float64 FFT.  The per-lane running top three are
+// kept as integer keys (|Z|^2 bits with the low 12 bits replaced by the bin), so windows
+// whose largest bins are closer than the relative band (default 5e-5, ~10x the f32 error)
+// plus the 2^-12 the keys drop are re-evaluated in float64: the two candidate bins by
+// direct summation with exactly reduced phases; if a third bin is in the band too, the
+// whole spectrum.
 #include <math.h>
 #include <stdlib.h>
 
@@ -41,22 +58,41 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define FLAG_TOP2 (1 << 30)
 #define FLAG_FULL (1 << 29)
 #define FLAG_MASK (FLAG_TOP2 | FLAG_FULL)
+#define KEY_BIN 0xFFFu   // low bits of a key hold the bin
+
+template <int I>
+using ic = std::integral_constant<int, I>;
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(ic<I>{}), ...);
+}
+// f(ic<0>), f(ic<1>), ... f(ic<N-1>): a loop whose index is a constant in every iteration
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 template <int N1, int N2>
 struct Plan {
+    static_assert(N1 % 2 == 1 && N2 % 2 == 1, "mirrored-pair folding needs odd factors");
     static constexpr int N = N1 * N2;
-    static constexpr int T1 = (N1 + 15) / 16;     // 16-row tiles over n1 (stage 1) / k1 (stage 2)
-    static constexpr int KS1 = (N2 + 3) / 4;      // stage-1 k-steps (4 values of b each)
-    static constexpr int K2 = N2 / 2 + 1;         // kept output columns k2
+    static constexpr int H1 = N1 / 2;             // a' and k1 run over [0, H1]
+    static constexpr int H2 = N2 / 2;             // b' and k2 run over [0, H2]
+    static constexpr int TA = (H1 + 1 + 15) / 16; // 16-row tiles over a' (stage 1) / k1 (stage 2)
+    static constexpr int T1 = 2 * TA;             // stage-1 row tiles: rows a', then rows n1-a'
+    static constexpr int KS1 = (H2 + 1 + 3) / 4;  // stage-1 k-steps (4 values of b' each)
+    static constexpr int K2 = H2 + 1;             // kept output columns k2
     static constexpr int C2T = (K2 + 15) / 16;    // 16-column tiles over k2
-    static constexpr int KS2 = (N1 + 3) / 4;      // stage-2 k-steps (4 values of a each)
+    static constexpr int KS2 = (H1 + 1 + 3) / 4;  // stage-2 k-steps (4 values of a' each)
+    static_assert(16 * TA <= N1 && KS2 <= 4 * TA && C2T >= 2 && C2T <= 4 && C2T <= T1 && N / 2 <= (int)KEY_BIN, "plan limits");
     static constexpr int NV4 = ((N + 3 + 3) / 4 + 63) / 64;  // float4 loads per lane per window
     static constexpr int XW = NV4 * 64 * 4;       // floats of LDS per wave
-    static constexpr int TW2 = (N2 + 1) & ~1;     // float2 entries, 16-byte multiple
-    static constexpr int EP = T1 * 4 * 64 * 4;    // uint16 entries of the output-bin table
+    static constexpr int TW1 = (N1 + 1) & ~1;     // float2 entries, 16-byte multiple
+    static constexpr int TW2 = (N2 + 1) & ~1;
+    static constexpr int EP = TA * 4 * 64 * 8;    // uint16 entries of the output-bin table
     // LDS map (bytes): stage-2 twiddles, stage-1 twiddles, output-bin table, class table, a
     // zero word, then one window buffer per wave
-    static constexpr int OFF_TW2 = N1 * 16;
+    static constexpr int OFF_TW2 = TW1 * 8;
     static constexpr int OFF_EP = OFF_TW2 + TW2 * 8;
     static constexpr int OFF_LUT = OFF_EP + EP * 2;
     static constexpr int OFF_ZERO = OFF_LUT + (((N / 2) * 2 + 15) & ~15);
@@ -64,42 +100,36 @@ struct Plan {
     static constexpr size_t LDS = (size_t)OFF_XW + (size_t)4 * XW * 4;
 };
 
+// The three largest keys seen.  A key is the bit pattern of a non-negative float with its
+// low 12 bits replaced by the bin: keys order like the values (to 2^-11), ties by bin.
 struct Top3 {
-    float m1, m2, m3;
-    int b1, b2;
+    unsigned k1, k2, k3;
+    float mx;   // exact largest value
 };
-
-// Keeps the three largest values seen and the bins of the first two.  Equal values are not
-// ordered by bin here: an exact tie leaves m2 == m1, which sends the window to the float64
-// pass, and that pass breaks ties towards the lower bin as np.argmax does.
-__device__ __forceinline__ void top3_insert(Top3 &t, float m, int b) {
-    const bool c1 = m > t.m1, c2 = m > t.m2;
-    // selects, never branches: the conditions are data-dependent per lane
-    const int b2a = __builtin_unpredictable(c2) ? b : t.b2;
-    t.b2 = __builtin_unpredictable(c1) ? t.b1 : b2a;
-    t.m3 = fmaxf(t.m3, fminf(m, t.m2));
-    t.m2 = __builtin_amdgcn_fmed3f(t.m1, t.m2, m);
-    t.b1 = __builtin_unpredictable(c1) ? b : t.b1;
-    t.m1 = fmaxf(t.m1, m);
+__device__ __forceinline__ void top3_insert(Top3 &t, unsigned key) {
+    t.k3 = max(t.k3, min(key, t.k2));
+    t.k2 = max(min(t.k1, t.k2), min(max(t.k1, t.k2), key));   // median of three
+    t.k1 = max(t.k1, key);
 }
 
 template <int N1, int N2>
 __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict__ audio, long long audio_len,
                                                         long long n_streams, long long stream_stride,
                                                         long long first_sample, long long n_windows,
-                                                        const float4 *__restrict__ g_tw1,
+                                                        const float2 *__restrict__ g_tw1,
                                                         const float2 *__restrict__ g_tw2,
                                                         const uint16_t *__restrict__ lut, int e1, int e2,
                                                         float keep, uint16_t *__restrict__ out_cls,
                                                         float *__restrict__ out_mag, int32_t *__restrict__ out_bin,
                                                         int dbg) {
     typedef Plan<N1, N2> P;
-    constexpr int N = P::N;
+    constexpr int N = P::N, TA = P::TA, T1 = P::T1, C2T = P::C2T, KS1 = P::KS1, KS2 = P::KS2;
+    constexpr int H1 = P::H1, H2 = P::H2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float *smf = (float *)smem;                        // everything below is indexed from here
-    float4 *tw1 = (float4 *)smem;                      // n1 x (cos, cos-sin, cos+sin, sin)(2*pi*m/n1)
+    float2 *tw1 = (float2 *)smem;                      // n1 x (cos, sin)(2*pi*m/n1)
     float2 *tw2 = (float2 *)(smem + P::OFF_TW2);       // n2 x (cos, -sin)(2*pi*m/n2)
-    uint16_t *ep = (uint16_t *)(smem + P::OFF_EP);     // [T1][4][64][4]: folded bin of an output, 0xFFFF = unused
+    uint16_t *ep = (uint16_t *)(smem + P::OFF_EP);     // [TA][4][64][8]: folded bin of an output, 0xFFFF = unused
     uint16_t *lut_s = (uint16_t *)(smem + P::OFF_LUT); // class word per bin
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -107,16 +137,18 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     for (int i = threadIdx.x; i < N2; i += 256) tw2[i] = g_tw2[i];
     for (int i = threadIdx.x; i < N / 2; i += 256) lut_s[i] = lut[i];
     if (threadIdx.x < 4) smf[P::OFF_ZERO / 4 + threadIdx.x] = 0.f;
-    // Output element (tile t, register r, column tile c) of lane l is Z[k1][k2] with
-    // k1 = 16t + 4(l>>4) + r, k2 = 16c + (l&15); its bin is (k1*e1 + k2*e2) mod N folded to
-    // [0, N/2].  Bins the reference never looks at, padding rows/columns and the mirrored
-    // half of column k2 = 0 are marked unused.
+    // Accumulator element (output tile t, register r, column tile c) of lane l holds the sums
+    // for k1 = 16t + 4(l>>4) + r, k2 = 16c + (l&15); from them come Z[k1][k2] (entry 2c) and
+    // Z[n1-k1][k2] (entry 2c+1).  The bin of Z[j][k2] is (j*e1 + k2*e2) mod N folded to
+    // [0, N/2].  Padding rows and columns, bins the reference never looks at, and the second
+    // copy of self-mirrored outputs (k1 = 0 or k2 = 0) are marked unused.
     for (int i = threadIdx.x; i < P::EP; i += 256) {
-        const int c = i & 3, l = (i >> 2) & 63, r = (i >> 8) & 3, t = i >> 10;
+        const int sg = i & 1, c = (i >> 1) & 3, l = (i >> 3) & 63, r = (i >> 9) & 3, t = i >> 11;
         const int k1 = 16 * t + 4 * (l >> 4) + r, k2 = 16 * c + (l & 15);
-        const int kb = (int)(((long long)k1 * e1 + (long long)k2 * e2) % N);
+        const int j = sg ? (N1 - k1) % N1 : k1;
+        const int kb = (int)(((long long)j * e1 + (long long)k2 * e2) % N);
         const int kk = min(kb, N - kb);
-        const bool ok = (c < P::C2T) & (k1 < N1) & (k2 < P::K2) & (kk < N / 2) & ((k2 != 0) | (k1 <= N1 / 2));
+        const bool ok = (c < C2T) & (k1 <= H1) & (k2 <= H2) & (kk < N / 2) & (!sg | ((k1 != 0) & (k2 != 0)));
         ep[i] = ok ? (uint16_t)kk : (uint16_t)0xFFFF;
     }
     __syncthreads();
@@ -127,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     const long long wstep = (long long)gridDim.x * 4;
     long long w = (long long)blockIdx.x * 4 + wave;
     const int xw_f = P::OFF_XW / 4 + wave * P::XW;     // float index of this wave's window buffer
+    constexpr int ZERO_F = P::OFF_ZERO / 4;
 
     // Window staging by LDS-DMA: 16 bytes per lane, 1 KiB per wave-instruction, written
     // to the wave's own LDS buffer at lds_base + 1024*j + 16*lane.  The loads are issued
@@ -189,20 +222,29 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         return (int)(g0 - a0);
     };
 
-    // per-lane starting indices of stage 1 (the same for every window)
-    int idxA0[P::T1];   // LDS index of x2[a(tile, li)][lg]; rows a >= n1 read real samples, their
-                        // products are dropped in stage 2 by a zero twiddle
-    int m20[P::C2T], st2[P::C2T];  // (b*k2) mod n2 at b = lg, and its step per k-step
+    // per-lane starting indices of stage 1 (the same for every window).  A-operand row li of
+    // row tile t is a' = 16(t mod TA) + 4(li&3) + (li>>2), i.e. result register r of lane group
+    // g holds a' = 16t + 4r + g, so that stage-2 k-step s covers a' = 4s .. 4s+3.  Tiles
+    // t >= TA hold row n1-a' at the position of a' (row 0 again for a' = 0).  Rows a' > H1
+    // are real samples too; their products are dropped in stage 2 by a zero twiddle.
+    int ipos0[T1], ineg0[T1];      // index of x2[a][b'] and x2[a][n2-b'] at b' = lg
+    int m20[C2T], st2[C2T];        // (b'*k2) mod n2 at b' = lg, and its step per k-step
 #pragma unroll
-    for (int t = 0; t < P::T1; ++t) idxA0[t] = (N2 * (16 * t + 4 * (li & 3) + (li >> 2)) + N1 * lg) % N;
+    for (int t = 0; t < T1; ++t) {
+        const int ap = 16 * (t % TA) + 4 * (li & 3) + (li >> 2);
+        const int a = t < TA ? ap : (N1 - ap) % N1;
+        ipos0[t] = (N2 * a + N1 * lg) % N;
+        ineg0[t] = (N2 * a + N - N1 * lg) % N;
+    }
 #pragma unroll
-    for (int c = 0; c < P::C2T; ++c) {
+    for (int c = 0; c < C2T; ++c) {
         int k2 = 16 * c + li;
-        k2 = k2 < P::K2 ? k2 : 0;
+        k2 = k2 <= H2 ? k2 : 0;
         m20[c] = (lg * k2) % N2;
         st2[c] = (4 * k2) % N2;
     }
     constexpr int STEP_A = (4 * N1) % N;
+    const float c_half = lg == 0 ? 0.5f : 1.0f;   // S of a' = 0 is 2*Y[0]
 
     // results of a window are stored one window later, just ahead of the next DMA, so that
     // the vmcnt(0) at the top of the loop never waits for a store it has just issued
@@ -222,82 +264,82 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     int next_off = 0;
     if (w < total) next_off = fetch(w);
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+    const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
 
     while (w < total) {
         const int xo = xw_f + next_off;   // float index of sample 0 of this window
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this window's DMA has landed
 
         // ------------------------------------------------------------------ stage 1
-        floatx4 Y[P::C2T][2][P::T1];
-        int idxA[P::T1], m2[P::C2T];
+        floatx4 Yr[C2T][T1], Yi[C2T][T1];
+        int ipos[T1], ineg[T1], m2[C2T];
 #pragma unroll
-        for (int t = 0; t < P::T1; ++t) idxA[t] = idxA0[t];
+        for (int t = 0; t < T1; ++t) {
+            ipos[t] = ipos0[t];
+            ineg[t] = ineg0[t];
+        }
 #pragma unroll
-        for (int c = 0; c < P::C2T; ++c) m2[c] = m20[c];
-        // LDS operands of one k-step (4 values of b): the samples of every row tile and the
-        // twiddles of every column tile, double-buffered in registers and read one k-step
-        // ahead of their MFMAs; the reads are pinned ahead of the MFMAs by sched_barrier.
-        int pa[P::T1], pt[P::C2T];
-        // address of row tile t / column tile c for k-step ks, then advance the index to ks + 1.
-        // Columns b >= n2 (only in the last k-step) read a zero word; the choice is made with
-        // bit masks so that it stays straight-line code.
-        auto addr_a = [&](int t, int ks) {
-            const int keep_m = -(int)(4 * ks + lg < N2);
-            pa[t] = ((xo + idxA[t]) & keep_m) | ((int)(P::OFF_ZERO / 4) & ~keep_m);
-            const int nx = idxA[t] + STEP_A;
-            idxA[t] = nx >= N ? nx - N : nx;
+        for (int c = 0; c < C2T; ++c) m2[c] = m20[c];
+        // LDS operands are read two k-steps ahead of their MFMAs (raw samples), folded one
+        // k-step ahead (xs = x[b'] + x[n2-b'], xd = x[b'] - x[n2-b']); twiddles one ahead.
+        float raw_p[T1], raw_m[T1], xs[2][T1], xd[2][T1];
+        float2 tw[2][C2T];
+        auto rd = [&](auto KS, auto T) {   // issue the sample reads of row tile T for k-step KS
+            constexpr int ks = decltype(KS)::value, t = decltype(T)::value;
+            int ap = xo + ipos[t], an = xo + ineg[t];
+            if constexpr (ks == 0) an = __builtin_unpredictable(lg == 0) ? ZERO_F : an;   // b' = 0 pairs with itself
+            if constexpr (4 * ks + 3 > H2) {                                               // b' > h2: no such column
+                const bool over = 4 * ks + lg > H2;
+                ap = __builtin_unpredictable(over) ? ZERO_F : ap;
+                an = __builtin_unpredictable(over) ? ZERO_F : an;
+            }
+            raw_p[t] = smf[ap];
+            raw_m[t] = smf[an];
         };
-        auto addr_t = [&](int c) {
-            pt[c] = m2[c];
+        auto adv = [&](auto T) {           // advance the sample indices of row tile T by one k-step
+            constexpr int t = decltype(T)::value;
+            const int np = ipos[t] + STEP_A, nn = ineg[t] - STEP_A;
+            ipos[t] = np >= N ? np - N : np;
+            ineg[t] = nn < 0 ? nn + N : nn;
+        };
+        auto fold = [&](auto B, auto T) {  // raw samples of row tile T -> operands of buffer B
+            constexpr int b = decltype(B)::value, t = decltype(T)::value;
+            xs[b][t] = raw_p[t] + raw_m[t];
+            xd[b][t] = raw_p[t] - raw_m[t];
+        };
+        auto rdtw = [&](auto B, auto C) {  // twiddles of column tile C into buffer B, advance
+            constexpr int b = decltype(B)::value, c = decltype(C)::value;
+            tw[b][c] = tw2[m2[c]];
             const int nx = m2[c] + st2[c];
             m2[c] = nx >= N2 ? nx - N2 : nx;
         };
-        float aA[P::T1], aB[P::T1];
-        float2 tA[P::C2T], tB[P::C2T];
-#define S1_ISSUE(A_, T_)                                                       \
-    do {                                                                       \
-        _Pragma("unroll") for (int t = 0; t < P::T1; ++t) A_[t] = smf[pa[t]];  \
-        _Pragma("unroll") for (int c = 0; c < P::C2T; ++c) T_[c] = tw2[pt[c]]; \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-    } while (0)
-        // One k-step: 2 MFMAs per (column tile, row tile) slot; each slot also carries a piece of
-        // the address arithmetic of k-step KS_NEXT_, pinned there so that it issues in the MFMA
-        // shadow instead of after the last MFMA.
-#define S1_MFMA(A_, T_, FIRST_, KS_NEXT_)                                                                     \
-    do {                                                                                                      \
-        _Pragma("unroll") for (int c = 0; c < P::C2T; ++c) {                                                  \
-            _Pragma("unroll") for (int t = 0; t < P::T1; ++t) {                                               \
-                const floatx4 z = {0.f, 0.f, 0.f, 0.f};                                                       \
-                Y[c][0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[t], T_[c].x, FIRST_ ? z : Y[c][0][t], 0, 0, 0); \
-                Y[c][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[t], T_[c].y, FIRST_ ? z : Y[c][1][t], 0, 0, 0); \
-                if (c == 0) addr_a(t, KS_NEXT_);                                                              \
-                if (c == P::C2T - 1 && t < P::C2T) addr_t(t);                                                 \
-                __builtin_amdgcn_sched_barrier(0);                                                            \
-            }                                                                                                 \
-        }                                                                                                     \
-    } while (0)
-#pragma unroll
-        for (int t = 0; t < P::T1; ++t) addr_a(t, 0);
-#pragma unroll
-        for (int c = 0; c < P::C2T; ++c) addr_t(c);
-        S1_ISSUE(aA, tA);                 // k-step 0
-#pragma unroll
-        for (int t = 0; t < P::T1; ++t) addr_a(t, 1);
-#pragma unroll
-        for (int c = 0; c < P::C2T; ++c) addr_t(c);
-        S1_ISSUE(aB, tB);                 // k-step 1
-        S1_MFMA(aA, tA, true, 2);         // k-step 0 starts the accumulators from a literal zero
-        const int ks_end = (dbg & 1) ? 2 : P::KS1;
-#pragma unroll 1
-        for (int ks = 1; ks + 1 < ks_end; ks += 2) {
-            S1_ISSUE(aA, tA);             // k-step ks + 1
-            S1_MFMA(aB, tB, false, ks + 2);   // k-step ks
-            S1_ISSUE(aB, tB);             // k-step ks + 2
-            S1_MFMA(aA, tA, false, ks + 3);   // k-step ks + 1
-        }
-        if ((P::KS1 - 1) % 2 == 1) S1_MFMA(aB, tB, false, P::KS1 + 1);   // last k-step when their number is even
-#undef S1_ISSUE
-#undef S1_MFMA
+        static_for<T1>([&](auto T) { rd(ic<0>{}, T); adv(T); });
+        static_for<C2T>([&](auto C) { rdtw(ic<0>{}, C); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<T1>([&](auto T) { fold(ic<0>{}, T); });
+        static_for<T1>([&](auto T) { rd(ic<1>{}, T); adv(T); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<KS1>([&](auto KS) {
+            constexpr int ks = decltype(KS)::value, cur = ks & 1, nxt = cur ^ 1;
+            static_for<C2T>([&](auto C) {
+                static_for<T1>([&](auto T) {
+                    constexpr int c = decltype(C)::value, t = decltype(T)::value;
+                    Yr[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cur][t], tw[cur][c].x, ks == 0 ? z4 : Yr[c][t], 0, 0, 0);
+                    Yi[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd[cur][t], tw[cur][c].y, ks == 0 ? z4 : Yi[c][t], 0, 0, 0);
+                    if constexpr (ks + 1 < KS1) {
+                        if constexpr (c == 0) {
+                            fold(ic<nxt>{}, T);
+                            if constexpr (ks + 2 < KS1) rd(ic<ks + 2>{}, T);
+                        }
+                        if constexpr (c == 1) {
+                            if constexpr (ks + 2 < KS1) adv(T);
+                            if constexpr (t < C2T) rdtw(ic<nxt>{}, T);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        });
 
         // every LDS read of this window has returned (its values fed the MFMAs above):
         // store the previous window's results, then start the next window's DMA so that it
@@ -308,134 +350,129 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         if (wn < total && !(dbg & 4)) next_off = fetch(wn);
 
         // ------------------------------------------------------------------ stage 2
-        // Z = W1 * (Yr + i*Yi) with three real products instead of four:
-        //   P1 = C*(Yr+Yi), P2 = (C-S)*Yi, P3 = (C+S)*Yr;  Re Z = P1 - P2, Im Z = P1 - P3.
-        floatx4 Ys[P::C2T][P::T1];
+        // rows a' and n1-a' -> sum and difference, in place: tiles [0, TA) hold S, [TA, 2TA) hold D
 #pragma unroll
-        for (int c = 0; c < P::C2T; ++c)
+        for (int c = 0; c < C2T; ++c)
 #pragma unroll
-            for (int t = 0; t < P::T1; ++t) Ys[c][t] = Y[c][0][t] + Y[c][1][t];
+            for (int t = 0; t < TA; ++t) {
+                const floatx4 ar = Yr[c][t], br = Yr[c][t + TA], ai = Yi[c][t], bi = Yi[c][t + TA];
+                Yr[c][t] = ar + br;
+                Yr[c][t + TA] = ar - br;
+                Yi[c][t] = ai + bi;
+                Yi[c][t + TA] = ai - bi;
+            }
 
         Top3 best;
-        best.m1 = best.m2 = best.m3 = -1.f;
-        best.b1 = best.b2 = 0x7fffffff;
-        // results of the previous output tile: their epilogue runs under this tile's MFMAs
-        float pre[P::C2T][4], pim[P::C2T][4];
-#pragma unroll
-        for (int c = 0; c < P::C2T; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pre[c][r] = pim[c][r] = 0.f;
-
-        // The epilogue of one output tile (12 elements: |Z|^2, bin lookup, top-3 update) is cut
-        // into five pieces per element and dealt out over the MFMA slots of the next tile, so
-        // that it issues in the shadow of the MFMAs.  Slots and pieces are generated at compile
-        // time (templated lambdas), every register index below is a constant.
-        uint2 ep_pk[4];
-        float ep_m[4 * P::C2T];
-        int ep_k[4 * P::C2T];
-        bool ep_c1[4 * P::C2T], ep_c2[4 * P::C2T];
-        int ep_t = -1;          // tile whose results are in pre/pim (-1: none)
-        auto piece = [&]<int Q>(std::integral_constant<int, Q>) {
-            constexpr int e = Q / 5, k = Q % 5, r = e / P::C2T, c = e % P::C2T;
+        best.k1 = best.k2 = best.k3 = 0u;
+        best.mx = 0.f;
+        // The four sums of an output tile; two sets, so that the epilogue of tile t (bins, |Z|^2,
+        // top-three update: 6 pieces per accumulator element) runs in the MFMA slots of tile t+1.
+        floatx4 acc[2][4][C2T];
+        uint4 ep_pk[4];
+        float e_rp, e_ip, e_rm, e_im, e_mp, e_mm;
+        unsigned e_kp, e_km;
+        auto piece = [&](auto TT, auto Q) {
+            constexpr int tt = decltype(TT)::value, q = decltype(Q)::value;
+            constexpr int e = q / 6, k = q % 6, r = e / C2T, c = e % C2T, set = tt & 1;
             if constexpr (k == 0) {
-                if constexpr (c == 0)
-                    ep_pk[r] = *(const uint2 *)(ep + ((((ep_t < 0 ? 0 : ep_t) * 4 + r) * 64 + lane) << 2));
+                if constexpr (c == 0) ep_pk[r] = *(const uint4 *)(ep + (((tt * 4 + r) * 64 + lane) << 3));
+                const float A = acc[set][0][c][r], B = acc[set][1][c][r], C = acc[set][2][c][r], E = acc[set][3][c][r];
+                e_rp = A + B;
+                e_ip = C - E;
+                e_rm = A - B;
+                e_im = C + E;
             } else if constexpr (k == 1) {
-                const unsigned word = c < 2 ? ep_pk[r].x : ep_pk[r].y;
-                const unsigned kk = (c & 1) ? (word >> 16) : (word & 0xFFFFu);
-                const bool ok = (kk != 0xFFFFu) & (ep_t >= 0);
-                const float mg = pre[c][r] * pre[c][r] + pim[c][r] * pim[c][r];
-                ep_m[e] = __builtin_unpredictable(ok) ? mg : -2.f;
-                ep_k[e] = (int)kk;
+                e_mp = e_rp * e_rp + e_ip * e_ip;
+                e_mm = e_rm * e_rm + e_im * e_im;
             } else if constexpr (k == 2) {
-                ep_c1[e] = ep_m[e] > best.m1;
-                ep_c2[e] = ep_m[e] > best.m2;
-                const int b2a = __builtin_unpredictable(ep_c2[e]) ? ep_k[e] : best.b2;
-                best.b2 = __builtin_unpredictable(ep_c1[e]) ? best.b1 : b2a;
+                const unsigned word = c == 0 ? ep_pk[r].x : (c == 1 ? ep_pk[r].y : (c == 2 ? ep_pk[r].z : ep_pk[r].w));
+                const unsigned kk = word & 0xFFFFu;
+                e_mp = __builtin_unpredictable(kk != 0xFFFFu) ? e_mp : 0.f;
+                e_kp = __builtin_unpredictable(kk != 0xFFFFu) ? ((__float_as_uint(e_mp) & ~KEY_BIN) | kk) : 0u;
             } else if constexpr (k == 3) {
-                best.m3 = fmaxf(best.m3, fminf(ep_m[e], best.m2));
-                best.m2 = __builtin_amdgcn_fmed3f(best.m1, best.m2, ep_m[e]);
+                const unsigned word = c == 0 ? ep_pk[r].x : (c == 1 ? ep_pk[r].y : (c == 2 ? ep_pk[r].z : ep_pk[r].w));
+                const unsigned kk = word >> 16;
+                e_mm = __builtin_unpredictable(kk != 0xFFFFu) ? e_mm : 0.f;
+                e_km = __builtin_unpredictable(kk != 0xFFFFu) ? ((__float_as_uint(e_mm) & ~KEY_BIN) | kk) : 0u;
+                best.mx = fmaxf(best.mx, fmaxf(e_mp, e_mm));
+            } else if constexpr (k == 4) {
+                top3_insert(best, e_kp);
             } else {
-                best.b1 = __builtin_unpredictable(ep_c1[e]) ? ep_k[e] : best.b1;
-                best.m1 = fmaxf(best.m1, ep_m[e]);
+                top3_insert(best, e_km);
             }
         };
-        constexpr int NPIECE = 5 * 4 * P::C2T;          // pieces per tile
-        constexpr int NSLOT = 3 * P::KS2;               // MFMA slots per tile (C2T MFMAs each)
-        auto pieces = [&]<int LO, int... J>(std::integral_constant<int, LO>, std::integer_sequence<int, J...>) {
-            (piece(std::integral_constant<int, LO + J>{}), ...);
+        constexpr int NPIECE = 6 * 4 * C2T;   // pieces per output tile
+        constexpr int NSLOT = 2 * KS2;        // MFMA slots per output tile (2*C2T MFMAs each)
+        // twiddles (cos, sin)(a'k1) of a k-step are read one k-step ahead (tw_pre), masked once
+        // (tw_cur) and serve its cosine half (sums A, C) and its sine half (sums B, E)
+        float2 tw_pre, tw_cur;
+        int m1, st1;
+        auto tile_start = [&](int tt) {   // twiddle index of k-step 0 and its step for output tile tt
+            const int k1a = 16 * tt + li; // A row of this lane
+            m1 = (k1a * lg) % N1;
+            st1 = (4 * k1a) % N1;
+            tw_pre = tw1[m1];
         };
-
-#pragma unroll 1
-        for (int t = 0; t < ((dbg & 2) ? 1 : P::T1); ++t) {
-            floatx4 p1[P::C2T], p2[P::C2T], p3[P::C2T];
-            const int k1a = 16 * t + li;  // A row of this lane
-            int m1 = (k1a * lg) % N1;
-            const int st1 = (4 * k1a) % N1;
-            float4 tw_next = tw1[m1], tw = tw_next;
-            ep_t = t - 1;
-            __builtin_amdgcn_sched_barrier(0);
-            // slot = (k-step s, product part): C2T MFMAs plus its share of the pending epilogue
-            auto slot = [&]<int SL>(std::integral_constant<int, SL>) {
-                constexpr int s = SL / 3, part = SL % 3;
-                const floatx4 z = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (part == 0) {
-                    tw = tw_next;
-                    if constexpr (4 * s + 3 >= N1) {   // rows a >= n1 of Y are not data: drop them
-                        const int keep_m = -(int)(4 * s + lg < N1);
-                        tw.x = __int_as_float(__float_as_int(tw.x) & keep_m);
-                        tw.y = __int_as_float(__float_as_int(tw.y) & keep_m);
-                        tw.z = __int_as_float(__float_as_int(tw.z) & keep_m);
+        tile_start(0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<TA>([&](auto TT) {
+            constexpr int tt = decltype(TT)::value, set = tt & 1;
+            static_for<NSLOT>([&](auto SL) {
+                constexpr int sl = decltype(SL)::value, s = sl >> 1, half = sl & 1, tau = s >> 2, r = s & 3;
+                if constexpr (half == 0) {
+                    tw_cur = tw_pre;
+                    if constexpr (s == 0) tw_cur.x *= c_half;
+                    if constexpr (4 * s + 3 > H1) {   // rows a' > h1 of S and D are not data: drop them
+                        const int keep_m = -(int)(4 * s + lg <= H1);
+                        tw_cur.x = __int_as_float(__float_as_int(tw_cur.x) & keep_m);
+                        tw_cur.y = __int_as_float(__float_as_int(tw_cur.y) & keep_m);
+                    }
+#pragma unroll
+                    for (int c = 0; c < C2T; ++c) {
+                        acc[set][0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw_cur.x, Yr[c][tau][r], s == 0 ? z4 : acc[set][0][c], 0, 0, 0);
+                        acc[set][2][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw_cur.x, Yi[c][tau][r], s == 0 ? z4 : acc[set][2][c], 0, 0, 0);
+                    }
+                    if constexpr (s + 1 < KS2) {
+                        const int nx = m1 + st1;
+                        m1 = nx >= N1 ? nx - N1 : nx;
+                        tw_pre = tw1[m1];
+                    } else if constexpr (tt + 1 < TA) {
+                        tile_start(tt + 1);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C2T; ++c) {
+                        acc[set][1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw_cur.y, Yi[c][tau + TA][r], s == 0 ? z4 : acc[set][1][c], 0, 0, 0);
+                        acc[set][3][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw_cur.y, Yr[c][tau + TA][r], s == 0 ? z4 : acc[set][3][c], 0, 0, 0);
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < P::C2T; ++c) {
-                    if constexpr (part == 0)
-                        p1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw.x, Ys[c][s >> 2][s & 3], s == 0 ? z : p1[c], 0, 0, 0);
-                    else if constexpr (part == 1)
-                        p2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw.y, Y[c][1][s >> 2][s & 3], s == 0 ? z : p2[c], 0, 0, 0);
-                    else
-                        p3[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw.z, Y[c][0][s >> 2][s & 3], s == 0 ? z : p3[c], 0, 0, 0);
+                if constexpr (tt > 0) {
+                    constexpr int lo = sl * NPIECE / NSLOT, hi = (sl + 1) * NPIECE / NSLOT;
+                    static_for<hi - lo>([&](auto J) { piece(ic<tt - 1>{}, ic<lo + decltype(J)::value>{}); });
                 }
-                if constexpr (part == 0) {   // twiddles of the next k-step, read ahead of its MFMAs
-                    const int nx = m1 + st1;
-                    m1 = nx >= N1 ? nx - N1 : nx;
-                    if constexpr (s + 1 < P::KS2) tw_next = tw1[m1];
-                }
-                constexpr int lo = SL * NPIECE / NSLOT, hi = (SL + 1) * NPIECE / NSLOT;
-                pieces(std::integral_constant<int, lo>{}, std::make_integer_sequence<int, hi - lo>{});
                 __builtin_amdgcn_sched_barrier(0);
-            };
-            [&]<int... I>(std::integer_sequence<int, I...>) {
-                (slot(std::integral_constant<int, I>{}), ...);
-            }(std::make_integer_sequence<int, NSLOT>{});
-#pragma unroll
-            for (int c = 0; c < P::C2T; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pre[c][r] = p1[c][r] - p2[c][r];
-                    pim[c][r] = p1[c][r] - p3[c][r];
-                }
-        }
-        ep_t = P::T1 - 1;
-        pieces(std::integral_constant<int, 0>{}, std::make_integer_sequence<int, NPIECE>{});
+            });
+        });
+        static_for<NPIECE>([&](auto Q) { piece(ic<TA - 1>{}, Q); });
         // wave-wide merge of the per-lane top three
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
-            const float om1 = __shfl_xor(best.m1, d), om2 = __shfl_xor(best.m2, d), om3 = __shfl_xor(best.m3, d);
-            const int ob1 = __shfl_xor(best.b1, d), ob2 = __shfl_xor(best.b2, d);
-            top3_insert(best, om1, ob1);
-            top3_insert(best, om2, ob2);
-            best.m3 = fmaxf(best.m3, om3);
+            const unsigned o1 = __shfl_xor(best.k1, d), o2 = __shfl_xor(best.k2, d), o3 = __shfl_xor(best.k3, d);
+            best.mx = fmaxf(best.mx, __shfl_xor(best.mx, d));
+            top3_insert(best, o1);
+            top3_insert(best, o2);
+            top3_insert(best, o3);
         }
         {
-            const bool silent = best.m1 <= 0.f;   // every bin is zero: np.argmax gives bin 0
-            const bool full = best.m3 >= best.m1 * keep, top2 = best.m2 >= best.m1 * keep;
-            const int b = silent ? 0 : best.b1;
+            const bool silent = best.mx <= 0.f;   // every bin is zero: np.argmax gives bin 0
+            const float f1 = __uint_as_float(best.k1 & ~KEY_BIN), f2 = __uint_as_float(best.k2 & ~KEY_BIN),
+                        f3 = __uint_as_float(best.k3 & ~KEY_BIN);
+            const bool full = f3 >= f1 * keep, top2 = f2 >= f1 * keep;
+            const int b = silent ? 0 : (int)(best.k1 & KEY_BIN);
             const unsigned cls = lut_s[b];
             pend_bin = silent ? 0 : (full ? (b | FLAG_FULL) : (top2 ? (b | FLAG_TOP2) : b));
-            pend_cls = silent ? cls : (full ? 0u : (top2 ? (unsigned)best.b2 : cls));
-            pend_mag = sqrtf(fmaxf(best.m1, 0.f));
+            pend_cls = silent ? cls : (full ? 0u : (top2 ? (best.k2 & KEY_BIN) : cls));
+            pend_mag = sqrtf(best.mx);
             pend_w = w;
             pend = true;
         }
@@ -574,7 +611,8 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     const long long total = n_streams * n_windows;
     long long blocks = (total + 3) / 4;
     if (blocks > ctx->num_cus) blocks = ctx->num_cus;
-    const double k = (1.0 - ctx->tie_band) * (1.0 - ctx->tie_band);
+    // squared magnitudes are compared, through keys that drop up to 2^-11 of the value
+    const double k = (1.0 - ctx->tie_band) * (1.0 - ctx->tie_band) / (1.0 + 1.0 / 2048.0) * (1.0 - 1e-6);
     hipLaunchKernelGGL((detect_kernel<N1, N2>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                        (long long)audio_len, (long long)n_streams, (long long)stream_stride,
                        (long long)first_sample, (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut,
