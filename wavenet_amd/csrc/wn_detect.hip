@@ -15,11 +15,12 @@
 //
 // Both stages fold their summation index in mirrored pairs (cos is even, sin is odd in the
 // index), which halves the multiplications, and stage 2 also produces rows k1 and n1-k1
-// from the same four real sums:
+// from the same four real sums.  With xs/xd = sum/difference of the mirrored columns b' and
+// n2-b' of x2, folded once more over the mirrored rows a' and n1-a':
 //
-//   stage 1, b' in [0, h2]:  Yr = sum cos(b'k2) (x2[a][b'] + x2[a][n2-b']),
-//                            Yi = -sum sin(b'k2) (x2[a][b'] - x2[a][n2-b'])
-//   stage 2, a' in [0, h1], k1 in [0, h1], with S = Y[a'] + Y[n1-a'], D = Y[a'] - Y[n1-a']:
+//   stage 1, b' in [0, h2]:  Sr = sum cos(b'k2) (xs[a'] + xs[n1-a']),  Dr = sum cos(b'k2) (xs[a'] - xs[n1-a'])
+//                            Si = -sum sin(b'k2) (xd[a'] + xd[n1-a']), Di = -sum sin(b'k2) (xd[a'] - xd[n1-a'])
+//   stage 2, a' in [0, h1], k1 in [0, h1]:
 //       A = sum cos(a'k1) Sr, B = sum sin(a'k1) Di, C = sum cos(a'k1) Si, E = sum sin(a'k1) Dr
 //       Z[k1] = (A + B) + i(C - E),   Z[n1-k1] = (A - B) + i(C + E)
 //
@@ -27,16 +28,17 @@
 // (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulation): 792 instructions of
 // 2048 FLOP per 7055-sample window (1.2 MFLOP useful) instead of the 99.5 MFLOP of a dense
 // N x N/2 DFT.  A stage-1 result tile is already laid out as the B operand of stage 2
-// (rows on register index and lane group); the mirrored rows n1-a' are computed as separate
-// row tiles with the same lane/register positions, so S and D are plain register adds and
-// Y never leaves the registers.
+// (rows on register index and lane group), so S and D never leave the registers.
 //
 // One wave owns one window at a time; a workgroup is four independent waves (one per
-// SIMD, the whole 512-entry register file each).  The window is staged in LDS by DMA
-// because the prime-factor index map is a gather; the next window is fetched while stage 2
-// runs.  With one wave per SIMD every instruction costs an issue slot, so the address
-// arithmetic, LDS reads and the arg-max epilogue are dealt out in fixed shares between the
-// MFMAs (compile-time generated slots) to issue in their shadow.
+// SIMD, the whole 512-entry register file each).  On this hardware a wave's own vector-ALU
+// and LDS instructions do not overlap with its matrix instructions, so the kernel is built
+// to issue as few of them as possible: every twiddle factor is a per-lane constant held in
+// registers for the whole launch (stage 1's in the accumulation registers, stage 2's in the
+// ordinary ones), the gather addresses of stage 1 are per-lane bases plus immediates (the
+// window is staged in LDS with a circular extension so that the index never wraps), and the
+// matrix instructions are issued in long uninterrupted runs.  The window is staged by DMA;
+// the next window is fetched while stage 2 runs.
 // Bound: matrix cores (f32 MFMA, 64 FLOP/clk/SIMD).
 //
 // Decisions must equal the reference's float64 FFT.  The per-lane running top three are
@@ -59,6 +61,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define FLAG_FULL (1 << 29)
 #define FLAG_MASK (FLAG_TOP2 | FLAG_FULL)
 #define KEY_BIN 0xFFFu   // low bits of a key hold the bin
+#define EP_UNUSED 0x8000u
 
 template <int I>
 using ic = std::integral_constant<int, I>;
@@ -79,25 +82,38 @@ struct Plan {
     static constexpr int H1 = N1 / 2;             // a' and k1 run over [0, H1]
     static constexpr int H2 = N2 / 2;             // b' and k2 run over [0, H2]
     static constexpr int TA = (H1 + 1 + 15) / 16; // 16-row tiles over a' (stage 1) / k1 (stage 2)
-    static constexpr int T1 = 2 * TA;             // stage-1 row tiles: rows a', then rows n1-a'
-    static constexpr int KS1 = (H2 + 1 + 3) / 4;  // stage-1 k-steps (4 values of b' each)
+    static constexpr int T1 = 2 * TA;             // stage-1 row tiles: sums over (a', n1-a'), then differences
+    static constexpr int KS1 = (H2 + 1 + 3) / 4;  // stage-1 k-steps; lane group g of k-step ks has b' = ks + KS1*g
     static constexpr int K2 = H2 + 1;             // kept output columns k2
     static constexpr int C2T = (K2 + 15) / 16;    // 16-column tiles over k2
-    static constexpr int KS2 = (H1 + 1 + 3) / 4;  // stage-2 k-steps (4 values of a' each)
-    static_assert(16 * TA <= N1 && KS2 <= 4 * TA && C2T >= 2 && C2T <= 4 && C2T <= T1 && N / 2 <= (int)KEY_BIN, "plan limits");
-    static constexpr int NV4 = ((N + 3 + 3) / 4 + 63) / 64;  // float4 loads per lane per window
-    static constexpr int XW = NV4 * 64 * 4;       // floats of LDS per wave
-    static constexpr int TW1 = (N1 + 1) & ~1;     // float2 entries, 16-byte multiple
-    static constexpr int TW2 = (N2 + 1) & ~1;
-    static constexpr int EP = TA * 4 * 64 * 8;    // uint16 entries of the output-bin table
-    // LDS map (bytes): stage-2 twiddles, stage-1 twiddles, output-bin table, class table, a
-    // zero word, then one window buffer per wave
-    static constexpr int OFF_TW2 = TW1 * 8;
-    static constexpr int OFF_EP = OFF_TW2 + TW2 * 8;
-    static constexpr int OFF_LUT = OFF_EP + EP * 2;
-    static constexpr int OFF_ZERO = OFF_LUT + (((N / 2) * 2 + 15) & ~15);
-    static constexpr int OFF_XW = OFF_ZERO + 16;
+    static constexpr int KS2 = (H1 + 1 + 3) / 4;  // stage-2 k-steps; lane group g of k-step s has a' = 4s + g
+    // window staging: SM floats by 16-byte DMA pieces, then NDW 4-byte pieces that finish the
+    // window and append its first EXT samples again (stage 1 reads up to EXT past the end)
+    static constexpr int SM = (N / 4) * 4;
+    static constexpr int NV4 = SM / 4;
+    static constexpr int EXT = N1 * (KS1 - 1);
+    static constexpr int NDW = (3 + N + EXT - SM + 63) / 64;
+    static constexpr int XW = (SM + 64 * NDW + 3) & ~3;   // floats of LDS per wave
+    static constexpr int EP = TA * 4 * 64 * 8;            // uint32 entries of the output-bin table
+    static_assert(16 * TA <= N1 && KS2 <= 4 * TA && C2T >= 2 && C2T <= 4 && N / 2 <= (int)KEY_BIN &&
+                      256 * (NDW - 1) < 4096 && 4 * N1 * (KS1 - 1) < 65536,
+                  "plan limits");
+    // LDS map (bytes): output-bin table, class table, then one window buffer per wave
+    static constexpr int OFF_LUT = EP * 4;
+    static constexpr int OFF_XW = OFF_LUT + (((N / 2) * 2 + 15) & ~15);
     static constexpr size_t LDS = (size_t)OFF_XW + (size_t)4 * XW * 4;
+    // idempotents of the index map: bin of Z[j][k2] is (j*E1 + k2*E2) mod N
+    static constexpr int idem(int own, int other) {
+        for (int x = other;; x += other)
+            if (x % own == 1) return x;
+    }
+    static constexpr int E1 = idem(N1, N2), E2 = idem(N2, N1);
+    // The one bin in [0, N/2] the reference never looks at is N/2 (N odd).  Its output sits at
+    // (k1x, k2x) on the plus side (Z[k1]) or the minus side (Z[n1-k1]) of a sum pair.
+    static constexpr int XB = ((N / 2) % N2 <= H2) ? N / 2 : N - N / 2;
+    static constexpr int XK2 = XB % N2, XJ = XB % N1;
+    static constexpr bool XMINUS = XJ > H1;
+    static constexpr int XK1 = XMINUS ? N1 - XJ : XJ;
 };
 
 // The three largest keys seen.  A key is the bit pattern of a non-negative float with its
@@ -112,46 +128,103 @@ __device__ __forceinline__ void top3_insert(Top3 &t, unsigned key) {
     t.k1 = max(t.k1, key);
 }
 
-template <int N1, int N2>
-__global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict__ audio, long long audio_len,
-                                                        long long n_streams, long long stream_stride,
-                                                        long long first_sample, long long n_windows,
-                                                        const float2 *__restrict__ g_tw1,
+// The matrix instruction, written out so that the register files are fixed: stage 1 reads its
+// B operand (constant twiddles) and keeps its sums in the accumulation registers; stage 2
+// reads those sums as its B operand where they are and keeps its own sums in ordinary
+// registers, where the arg-max code reads them.  (Left to the compiler, operands are copied
+// between the two files inside the window loop.)  The compiler does not see inside: the
+// code below keeps 16 wait states between the last MFMA writing a register and the first
+// other instruction reading it.
+__device__ __forceinline__ void mfma1_acc(floatx4 &y, float a, float b_acc) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(y) : "v"(a), "a"(b_acc));
+}
+__device__ __forceinline__ void mfma1_new(floatx4 &y, float a, float b_acc) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(y) : "v"(a), "a"(b_acc));
+}
+__device__ __forceinline__ void mfma2_acc(floatx4 &acc, float a, float b_acc) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_acc));
+}
+__device__ __forceinline__ void mfma2_new(floatx4 &acc, float a, float b_acc) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b_acc));
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
+// a value that lives in an accumulation register from here on
+__device__ __forceinline__ void acc_const(float &dst, float v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); }
+// ties a register's later readers to this point of the (ordered) asm sequence
+__device__ __forceinline__ void after_drain(floatx4 &v) { asm volatile("" : "+v"(v)); }
+
+// CNT loads of 16 (X4) or 4 bytes per lane from p + j*STRIDE bytes straight into LDS at
+// lds + j*STRIDE + lane*(16 or 4): the immediate offset applies to both addresses.  M0 holds
+// the LDS base for the duration and is restored.
+template <int CNT, int STRIDE, bool X4>
+__device__ __forceinline__ void dma_group(const float *p, unsigned lds) {
+    static_assert(CNT >= 1 && CNT <= 4, "group size");
+    unsigned keep_m0;
+#define WN_DMA_ASM(OP)                                                                                       \
+    if constexpr (CNT == 1)                                                                                  \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_m0) : "v"(p), "s"(lds) : "memory");                                        \
+    else if constexpr (CNT == 2)                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
+                     " %1, off offset:%3\n\ts_mov_b32 m0, %0"                                                \
+                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE) : "memory");                           \
+    else if constexpr (CNT == 3)                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
+                     " %1, off offset:%3\n\t" OP " %1, off offset:%4\n\ts_mov_b32 m0, %0"                    \
+                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE), "n"(2 * STRIDE) : "memory");          \
+    else                                                                                                     \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
+                     " %1, off offset:%3\n\t" OP " %1, off offset:%4\n\t" OP                                 \
+                     " %1, off offset:%5\n\ts_mov_b32 m0, %0"                                                \
+                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE)      \
+                     : "memory");
+    if constexpr (X4) {
+        WN_DMA_ASM("global_load_lds_dwordx4")
+    } else {
+        WN_DMA_ASM("global_load_lds_dword")
+    }
+#undef WN_DMA_ASM
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+template <int N1, int N2, bool PROF>
+__global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict__ audio, long long n_streams,
+                                                        long long stream_stride, long long first_sample,
+                                                        long long n_windows, const float2 *__restrict__ g_tw1,
                                                         const float2 *__restrict__ g_tw2,
-                                                        const uint16_t *__restrict__ lut, int e1, int e2,
-                                                        float keep, uint16_t *__restrict__ out_cls,
-                                                        float *__restrict__ out_mag, int32_t *__restrict__ out_bin,
-                                                        int dbg) {
+                                                        const uint16_t *__restrict__ lut, float keep,
+                                                        uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
+                                                        int32_t *__restrict__ out_bin) {
     typedef Plan<N1, N2> P;
     constexpr int N = P::N, TA = P::TA, T1 = P::T1, C2T = P::C2T, KS1 = P::KS1, KS2 = P::KS2;
     constexpr int H1 = P::H1, H2 = P::H2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    float *smf = (float *)smem;                        // everything below is indexed from here
-    float2 *tw1 = (float2 *)smem;                      // n1 x (cos, sin)(2*pi*m/n1)
-    float2 *tw2 = (float2 *)(smem + P::OFF_TW2);       // n2 x (cos, -sin)(2*pi*m/n2)
-    uint16_t *ep = (uint16_t *)(smem + P::OFF_EP);     // [TA][4][64][8]: folded bin of an output, 0xFFFF = unused
-    uint16_t *lut_s = (uint16_t *)(smem + P::OFF_LUT); // class word per bin
+    float *smf = (float *)smem;
+    uint32_t *ep = (uint32_t *)smem;                    // [TA][4][64][8]: folded bin of an output, bit 15 = unused
+    uint16_t *lut_s = (uint16_t *)(smem + P::OFF_LUT);  // class word per bin
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < N1; i += 256) tw1[i] = g_tw1[i];
-    for (int i = threadIdx.x; i < N2; i += 256) tw2[i] = g_tw2[i];
     for (int i = threadIdx.x; i < N / 2; i += 256) lut_s[i] = lut[i];
-    if (threadIdx.x < 4) smf[P::OFF_ZERO / 4 + threadIdx.x] = 0.f;
     // Accumulator element (output tile t, register r, column tile c) of lane l holds the sums
     // for k1 = 16t + 4(l>>4) + r, k2 = 16c + (l&15); from them come Z[k1][k2] (entry 2c) and
-    // Z[n1-k1][k2] (entry 2c+1).  The bin of Z[j][k2] is (j*e1 + k2*e2) mod N folded to
-    // [0, N/2].  Padding rows and columns, bins the reference never looks at, and the second
-    // copy of self-mirrored outputs (k1 = 0 or k2 = 0) are marked unused.
+    // Z[n1-k1][k2] (entry 2c+1).  The bin of Z[j][k2] is (j*E1 + k2*E2) mod N folded to
+    // [0, N/2].  Padding rows and columns (whose sums are exactly zero), the bin the
+    // reference never looks at, and the second copy of self-mirrored outputs (k1 = 0 or
+    // k2 = 0) are marked unused.
     for (int i = threadIdx.x; i < P::EP; i += 256) {
         const int sg = i & 1, c = (i >> 1) & 3, l = (i >> 3) & 63, r = (i >> 9) & 3, t = i >> 11;
         const int k1 = 16 * t + 4 * (l >> 4) + r, k2 = 16 * c + (l & 15);
         const int j = sg ? (N1 - k1) % N1 : k1;
-        const int kb = (int)(((long long)j * e1 + (long long)k2 * e2) % N);
+        const int kb = (int)(((long long)j * P::E1 + (long long)k2 * P::E2) % N);
         const int kk = min(kb, N - kb);
         const bool ok = (c < C2T) & (k1 <= H1) & (k2 <= H2) & (kk < N / 2) & (!sg | ((k1 != 0) & (k2 != 0)));
-        ep[i] = ok ? (uint16_t)kk : (uint16_t)0xFFFF;
+        const bool pad = (c >= C2T) | (k1 > H1) | (k2 > H2);
+        ep[i] = ok ? (uint32_t)kk : (pad ? KEY_BIN : (EP_UNUSED | KEY_BIN));
     }
-    __syncthreads();
 
     const int li = lane & 15;  // A row / B column / D column
     const int lg = lane >> 4;  // A,B k index / D row group
@@ -159,95 +232,100 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     const long long wstep = (long long)gridDim.x * 4;
     long long w = (long long)blockIdx.x * 4 + wave;
     const int xw_f = P::OFF_XW / 4 + wave * P::XW;     // float index of this wave's window buffer
-    constexpr int ZERO_F = P::OFF_ZERO / 4;
-
-    // Window staging by LDS-DMA: 16 bytes per lane, 1 KiB per wave-instruction, written
-    // to the wave's own LDS buffer at lds_base + 1024*j + 16*lane.  The loads are issued
-    // from inline asm so that the compiler does not order the table reads of stage 2
-    // behind them; the wait is the explicit vmcnt(0) at the top of the window loop.
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(smf + xw_f);
-    auto fetch = [&](long long win) {
-        const long long s = win / n_windows;
-        const long long wi = win - s * n_windows;
-        const long long g0 = s * stream_stride + first_sample + wi * (long long)N;
-        const long long a0 = g0 & ~3ll;
-        if (a0 + 256ll * P::NV4 <= audio_len) {
-            // whole span inside the buffer: one address per 4 KiB, immediate offsets (which the
-            // hardware adds to the global and to the LDS address alike) for the 1-KiB pieces
-            const float *src = audio + a0 + 4 * lane;
-#pragma unroll
-            for (int j = 0; j < P::NV4; j += 4) {
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 1024u * j);
-                unsigned keep_m0;
-                if (j + 4 <= P::NV4) {
-                    asm volatile(
-                        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                        "global_load_lds_dwordx4 %1, off\n\t"
-                        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-                        "s_mov_b32 m0, %0"
-                        : "=&s"(keep_m0)
-                        : "v"(src + 256 * j), "s"(dst)
-                        : "memory");
-                } else {
-#pragma unroll
-                    for (int u = 0; u < P::NV4 - j; ++u) {
-                        const unsigned d2 = __builtin_amdgcn_readfirstlane(lds_base + 1024u * (j + u));
-                        asm volatile(
-                            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                            "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                            : "=&s"(keep_m0)
-                            : "v"(src + 256 * (j + u)), "s"(d2)
-                            : "memory");
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < P::NV4; ++j) {
-                long long e = a0 + 4 * (j * 64 + lane);
-                e = e + 4 <= audio_len ? e : audio_len - 4;  // pieces past the window are never read
-                const float *src = audio + e;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 1024u * j);
-                unsigned keep_m0;
-                asm volatile(
-                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                    "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                    : "=&s"(keep_m0)
-                    : "v"(src), "s"(dst)
-                    : "memory");
-            }
-        }
-        return (int)(g0 - a0);
-    };
 
-    // per-lane starting indices of stage 1 (the same for every window).  A-operand row li of
-    // row tile t is a' = 16(t mod TA) + 4(li&3) + (li>>2), i.e. result register r of lane group
-    // g holds a' = 16t + 4r + g, so that stage-2 k-step s covers a' = 4s .. 4s+3.  Tiles
-    // t >= TA hold row n1-a' at the position of a' (row 0 again for a' = 0).  Rows a' > H1
-    // are real samples too; their products are dropped in stage 2 by a zero twiddle.
-    int ipos0[T1], ineg0[T1];      // index of x2[a][b'] and x2[a][n2-b'] at b' = lg
-    int m20[C2T], st2[C2T];        // (b'*k2) mod n2 at b' = lg, and its step per k-step
+    // ---- per-lane constants, held in registers for the whole launch
+    // stage-1 twiddles (B operand: row b' = ks + KS1*lg, column k2 = 16c + li), in accumulation
+    // registers: (cos, -sin)(2*pi*b'*k2/n2); zero for padding rows and columns; cos halved
+    // for b' = 0, whose folded sample is x2[a][0] twice
+    float t2c[KS1][C2T], t2s[KS1][C2T];
+    static_for<KS1>([&](auto KS) {
+        static_for<C2T>([&](auto C) {
+            constexpr int ks = decltype(KS)::value, c = decltype(C)::value;
+            const int bp = ks + KS1 * lg, k2 = 16 * c + li;
+            float2 t = g_tw2[(bp * k2) % N2];
+            if (bp > H2 || k2 > H2) t = make_float2(0.f, 0.f);
+            if (bp == 0) t.x *= 0.5f;
+            acc_const(t2c[ks][c], t.x);
+            acc_const(t2s[ks][c], t.y);
+        });
+    });
+    // stage-2 twiddles (A operand: row k1 = 16t + li, column a' = 4s + lg), in ordinary
+    // registers: (cos, sin)(2*pi*a'*k1/n1); zero for padding rows and columns; cos halved
+    // for a' = 0, whose folded row is Y[0] twice
+    float t1c[TA][KS2], t1s[TA][KS2];
+    static_for<TA>([&](auto TT) {
+        static_for<KS2>([&](auto S) {
+            constexpr int tt = decltype(TT)::value, s = decltype(S)::value;
+            const int k1 = 16 * tt + li, ap = 4 * s + lg;
+            float2 t = g_tw1[(k1 * ap) % N1];
+            if (ap > H1 || k1 > H1) t = make_float2(0.f, 0.f);
+            if (ap == 0) t.x *= 0.5f;
+            t1c[tt][s] = t.x;
+            t1s[tt][s] = t.y;
+        });
+    });
+    // stage-1 gather: A-operand row li of row tile t is a' = 16(t mod TA) + 4(li&3) + (li>>2),
+    // i.e. result register r of lane group g holds a' = 16t + 4r + g, so that stage-2 k-step s
+    // covers a' = 4s .. 4s+3; tiles t >= TA read row n1-a' (row 0 again for a' = 0: its
+    // difference is zero and its sum is halved by the twiddle).  Column b' of row a is sample
+    // (n2*a + n1*b') mod N and column n2-b' is sample (n2*a - n1*b') mod N; over the k-steps
+    // the first index climbs by n1 from its value at ks = 0 and the second descends by n1 to
+    // its value at ks = KS1-1, both without reduction thanks to the circular extension.
+    int cb_p[T1], cb_m[T1];   // byte offsets from sample 0 of the window
 #pragma unroll
     for (int t = 0; t < T1; ++t) {
         const int ap = 16 * (t % TA) + 4 * (li & 3) + (li >> 2);
         const int a = t < TA ? ap : (N1 - ap) % N1;
-        ipos0[t] = (N2 * a + N1 * lg) % N;
-        ineg0[t] = (N2 * a + N - N1 * lg) % N;
+        cb_p[t] = 4 * ((N2 * a + N1 * (KS1 * lg)) % N);
+        cb_m[t] = 4 * ((N2 * a + N * N1 - N1 * (KS1 - 1 + KS1 * lg)) % N);
     }
-#pragma unroll
-    for (int c = 0; c < C2T; ++c) {
-        int k2 = 16 * c + li;
-        k2 = k2 <= H2 ? k2 : 0;
-        m20[c] = (lg * k2) % N2;
-        st2[c] = (4 * k2) % N2;
-    }
-    constexpr int STEP_A = (4 * N1) % N;
-    const float c_half = lg == 0 ? 0.5f : 1.0f;   // S of a' = 0 is 2*Y[0]
+    __syncthreads();
 
-    // results of a window are stored one window later, just ahead of the next DMA, so that
-    // the vmcnt(0) at the top of the loop never waits for a store it has just issued
+    // ---- window staging by LDS-DMA
+    auto fetch = [&](long long s, long long wi) {
+        const long long g0 = s * stream_stride + first_sample + wi * (long long)N;
+        const int off = (int)(g0 & 3);
+        const float *x0 = audio + g0;
+        // 16-byte pieces: floats [0, SM) of the buffer <- samples [-off, SM - off)
+        const float *src = x0 - off + 4 * lane;
+        constexpr int FULL = P::NV4 / 64, REM = P::NV4 % 64;
+        static_for<(FULL + 3) / 4>([&](auto G) {
+            constexpr int g = decltype(G)::value, cnt = FULL - 4 * g < 4 ? FULL - 4 * g : 4;
+            dma_group<cnt, 1024, true>(src + 1024 * g, __builtin_amdgcn_readfirstlane(lds_base + 4096u * g));
+        });
+        if constexpr (REM > 0) {
+            if (lane < REM)
+                dma_group<1, 1024, true>(src + 256 * FULL, __builtin_amdgcn_readfirstlane(lds_base + 1024u * FULL));
+        }
+        // 4-byte pieces: floats [SM, SM + 64*NDW) <- the last samples of the window, then its
+        // first ones again.  Only the first piece contains the seam.
+        const int i0 = P::SM + lane - off;
+        dma_group<1, 256, false>(x0 + (i0 < N ? i0 : i0 - N), __builtin_amdgcn_readfirstlane(lds_base + 4u * P::SM));
+        const float *ext = x0 + (P::SM + 64 + lane - off - N);
+        static_for<(P::NDW - 1 + 3) / 4>([&](auto G) {
+            constexpr int g = decltype(G)::value, cnt = P::NDW - 1 - 4 * g < 4 ? P::NDW - 1 - 4 * g : 4;
+            dma_group<cnt, 256, false>(ext + 256 * g,
+                                       __builtin_amdgcn_readfirstlane(lds_base + 4u * (P::SM + 64) + 1024u * g));
+        });
+        return off;
+    };
+    // (stream, window) of the window to fetch next, advanced without divisions
+    const long long adv_s = wstep / n_windows, adv_w = wstep - adv_s * n_windows;
+    long long f_s = w / n_windows, f_w = w - f_s * n_windows;
+    auto fetch_next = [&]() {
+        const int off = fetch(f_s, f_w);
+        f_s += adv_s;
+        f_w += adv_w;
+        if (f_w >= n_windows) {
+            f_w -= n_windows;
+            f_s += 1;
+        }
+        return off;
+    };
+
+    // Results of a window are stored one window later, just ahead of the next DMA issue, so
+    // that the wait for DMA data never waits for a store just issued.
     bool pend = false;
     long long pend_w = 0;
     int pend_bin = 0;
@@ -261,208 +339,177 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         }
     };
 
+    // PROF build only: shader clocks spent per phase of the window loop, summed over this wave's windows
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = 0;
+    const unsigned long long prof_r0 = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long prof_c0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto lap = [&](auto I) {
+        if constexpr (PROF) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            prof[decltype(I)::value] += now - prof_t;
+            prof_t = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     int next_off = 0;
-    if (w < total) next_off = fetch(w);
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-    const floatx4 z4 = {0.f, 0.f, 0.f, 0.f};
-
+    if (w < total) next_off = fetch_next();
     while (w < total) {
-        const int xo = xw_f + next_off;   // float index of sample 0 of this window
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this window's DMA has landed
-
-        // ------------------------------------------------------------------ stage 1
-        floatx4 Yr[C2T][T1], Yi[C2T][T1];
-        int ipos[T1], ineg[T1], m2[C2T];
+        if constexpr (PROF) prof_t = __builtin_amdgcn_s_memtime();
+        const int xb = 4 * (xw_f + next_off);   // byte address of sample 0 of this window
+        int ad_p[T1], ad_m[T1];
 #pragma unroll
         for (int t = 0; t < T1; ++t) {
-            ipos[t] = ipos0[t];
-            ineg[t] = ineg0[t];
+            ad_p[t] = xb + cb_p[t];
+            ad_m[t] = xb + cb_m[t];
         }
-#pragma unroll
-        for (int c = 0; c < C2T; ++c) m2[c] = m20[c];
-        // LDS operands are read two k-steps ahead of their MFMAs (raw samples), folded one
-        // k-step ahead (xs = x[b'] + x[n2-b'], xd = x[b'] - x[n2-b']); twiddles one ahead.
-        float raw_p[T1], raw_m[T1], xs[2][T1], xd[2][T1];
-        float2 tw[2][C2T];
-        auto rd = [&](auto KS, auto T) {   // issue the sample reads of row tile T for k-step KS
-            constexpr int ks = decltype(KS)::value, t = decltype(T)::value;
-            int ap = xo + ipos[t], an = xo + ineg[t];
-            if constexpr (ks == 0) an = __builtin_unpredictable(lg == 0) ? ZERO_F : an;   // b' = 0 pairs with itself
-            if constexpr (4 * ks + 3 > H2) {                                               // b' > h2: no such column
-                const bool over = 4 * ks + lg > H2;
-                ap = __builtin_unpredictable(over) ? ZERO_F : ap;
-                an = __builtin_unpredictable(over) ? ZERO_F : an;
-            }
-            raw_p[t] = smf[ap];
-            raw_m[t] = smf[an];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this window's DMA has landed
+        lap(ic<0>{});
+
+        // ------------------------------------------------------------------ stage 1
+        floatx4 Yr[C2T][T1], Yi[C2T][T1];   // S (row tiles < TA) and D (row tiles >= TA), real and imaginary
+        float raw_p[T1], raw_m[T1], xs[T1], xd[T1];
+        auto rd = [&](auto KS) {   // issue the sample reads of k-step KS
+            constexpr int ks = decltype(KS)::value;
+            static_for<T1>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                raw_p[t] = *(const float *)(smem + ad_p[t] + 4 * N1 * ks);
+                raw_m[t] = *(const float *)(smem + ad_m[t] + 4 * N1 * (KS1 - 1 - ks));
+            });
         };
-        auto adv = [&](auto T) {           // advance the sample indices of row tile T by one k-step
-            constexpr int t = decltype(T)::value;
-            const int np = ipos[t] + STEP_A, nn = ineg[t] - STEP_A;
-            ipos[t] = np >= N ? np - N : np;
-            ineg[t] = nn < 0 ? nn + N : nn;
+        auto fold = [&]() {        // samples read last -> A operands: fold columns, then rows
+            static_for<TA>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                const float sa = raw_p[t] + raw_m[t], da = raw_p[t] - raw_m[t];
+                const float sb = raw_p[t + TA] + raw_m[t + TA], db = raw_p[t + TA] - raw_m[t + TA];
+                xs[t] = sa + sb;
+                xs[t + TA] = sa - sb;
+                xd[t] = da + db;
+                xd[t + TA] = da - db;
+            });
         };
-        auto fold = [&](auto B, auto T) {  // raw samples of row tile T -> operands of buffer B
-            constexpr int b = decltype(B)::value, t = decltype(T)::value;
-            xs[b][t] = raw_p[t] + raw_m[t];
-            xd[b][t] = raw_p[t] - raw_m[t];
-        };
-        auto rdtw = [&](auto B, auto C) {  // twiddles of column tile C into buffer B, advance
-            constexpr int b = decltype(B)::value, c = decltype(C)::value;
-            tw[b][c] = tw2[m2[c]];
-            const int nx = m2[c] + st2[c];
-            m2[c] = nx >= N2 ? nx - N2 : nx;
-        };
-        static_for<T1>([&](auto T) { rd(ic<0>{}, T); adv(T); });
-        static_for<C2T>([&](auto C) { rdtw(ic<0>{}, C); });
+        rd(ic<0>{});
         __builtin_amdgcn_sched_barrier(0);
-        static_for<T1>([&](auto T) { fold(ic<0>{}, T); });
-        static_for<T1>([&](auto T) { rd(ic<1>{}, T); adv(T); });
+        fold();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KS1 > 1) rd(ic<1>{});
         __builtin_amdgcn_sched_barrier(0);
         static_for<KS1>([&](auto KS) {
-            constexpr int ks = decltype(KS)::value, cur = ks & 1, nxt = cur ^ 1;
+            constexpr int ks = decltype(KS)::value;
             static_for<C2T>([&](auto C) {
                 static_for<T1>([&](auto T) {
                     constexpr int c = decltype(C)::value, t = decltype(T)::value;
-                    Yr[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[cur][t], tw[cur][c].x, ks == 0 ? z4 : Yr[c][t], 0, 0, 0);
-                    Yi[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xd[cur][t], tw[cur][c].y, ks == 0 ? z4 : Yi[c][t], 0, 0, 0);
-                    if constexpr (ks + 1 < KS1) {
-                        if constexpr (c == 0) {
-                            fold(ic<nxt>{}, T);
-                            if constexpr (ks + 2 < KS1) rd(ic<ks + 2>{}, T);
-                        }
-                        if constexpr (c == 1) {
-                            if constexpr (ks + 2 < KS1) adv(T);
-                            if constexpr (t < C2T) rdtw(ic<nxt>{}, T);
-                        }
+                    if constexpr (ks == 0) {
+                        mfma1_new(Yr[c][t], xs[t], t2c[ks][c]);
+                        mfma1_new(Yi[c][t], xd[t], t2s[ks][c]);
+                    } else {
+                        mfma1_acc(Yr[c][t], xs[t], t2c[ks][c]);
+                        mfma1_acc(Yi[c][t], xd[t], t2s[ks][c]);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 });
             });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ks + 1 < KS1) {
+                fold();                                    // operands of k-step ks+1 (read before this k-step's MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ks + 2 < KS1)
+                    rd(ic<ks + 2>{});
+                else
+                    asm volatile("s_nop 1" ::: "memory");   // operands just written, read by the next MFMA
+                __builtin_amdgcn_sched_barrier(0);
+            }
         });
+        lap(ic<1>{});
 
         // every LDS read of this window has returned (its values fed the MFMAs above):
         // store the previous window's results, then start the next window's DMA so that it
         // lands while stage 2 runs
         const long long wn = w + wstep;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         flush();
-        if (wn < total && !(dbg & 4)) next_off = fetch(wn);
+        if (wn < total) next_off = fetch_next();
+        lap(ic<2>{});
+        mfma_drain();
 
         // ------------------------------------------------------------------ stage 2
-        // rows a' and n1-a' -> sum and difference, in place: tiles [0, TA) hold S, [TA, 2TA) hold D
-#pragma unroll
-        for (int c = 0; c < C2T; ++c)
-#pragma unroll
-            for (int t = 0; t < TA; ++t) {
-                const floatx4 ar = Yr[c][t], br = Yr[c][t + TA], ai = Yi[c][t], bi = Yi[c][t + TA];
-                Yr[c][t] = ar + br;
-                Yr[c][t + TA] = ar - br;
-                Yi[c][t] = ai + bi;
-                Yi[c][t + TA] = ai - bi;
-            }
-
         Top3 best;
         best.k1 = best.k2 = best.k3 = 0u;
         best.mx = 0.f;
-        // The four sums of an output tile; two sets, so that the epilogue of tile t (bins, |Z|^2,
-        // top-three update: 6 pieces per accumulator element) runs in the MFMA slots of tile t+1.
-        floatx4 acc[2][4][C2T];
-        uint4 ep_pk[4];
-        float e_rp, e_ip, e_rm, e_im, e_mp, e_mm;
-        unsigned e_kp, e_km;
-        auto piece = [&](auto TT, auto Q) {
-            constexpr int tt = decltype(TT)::value, q = decltype(Q)::value;
-            constexpr int e = q / 6, k = q % 6, r = e / C2T, c = e % C2T, set = tt & 1;
-            if constexpr (k == 0) {
-                if constexpr (c == 0) ep_pk[r] = *(const uint4 *)(ep + (((tt * 4 + r) * 64 + lane) << 3));
-                const float A = acc[set][0][c][r], B = acc[set][1][c][r], C = acc[set][2][c][r], E = acc[set][3][c][r];
-                e_rp = A + B;
-                e_ip = C - E;
-                e_rm = A - B;
-                e_im = C + E;
-            } else if constexpr (k == 1) {
-                e_mp = e_rp * e_rp + e_ip * e_ip;
-                e_mm = e_rm * e_rm + e_im * e_im;
-            } else if constexpr (k == 2) {
-                const unsigned word = c == 0 ? ep_pk[r].x : (c == 1 ? ep_pk[r].y : (c == 2 ? ep_pk[r].z : ep_pk[r].w));
-                const unsigned kk = word & 0xFFFFu;
-                e_mp = __builtin_unpredictable(kk != 0xFFFFu) ? e_mp : 0.f;
-                e_kp = __builtin_unpredictable(kk != 0xFFFFu) ? ((__float_as_uint(e_mp) & ~KEY_BIN) | kk) : 0u;
-            } else if constexpr (k == 3) {
-                const unsigned word = c == 0 ? ep_pk[r].x : (c == 1 ? ep_pk[r].y : (c == 2 ? ep_pk[r].z : ep_pk[r].w));
-                const unsigned kk = word >> 16;
-                e_mm = __builtin_unpredictable(kk != 0xFFFFu) ? e_mm : 0.f;
-                e_km = __builtin_unpredictable(kk != 0xFFFFu) ? ((__float_as_uint(e_mm) & ~KEY_BIN) | kk) : 0u;
-                best.mx = fmaxf(best.mx, fmaxf(e_mp, e_mm));
-            } else if constexpr (k == 4) {
-                top3_insert(best, e_kp);
-            } else {
-                top3_insert(best, e_km);
-            }
-        };
-        constexpr int NPIECE = 6 * 4 * C2T;   // pieces per output tile
-        constexpr int NSLOT = 2 * KS2;        // MFMA slots per output tile (2*C2T MFMAs each)
-        // twiddles (cos, sin)(a'k1) of a k-step are read one k-step ahead (tw_pre), masked once
-        // (tw_cur) and serve its cosine half (sums A, C) and its sine half (sums B, E)
-        float2 tw_pre, tw_cur;
-        int m1, st1;
-        auto tile_start = [&](int tt) {   // twiddle index of k-step 0 and its step for output tile tt
-            const int k1a = 16 * tt + li; // A row of this lane
-            m1 = (k1a * lg) % N1;
-            st1 = (4 * k1a) % N1;
-            tw_pre = tw1[m1];
-        };
-        tile_start(0);
-        __builtin_amdgcn_sched_barrier(0);
         static_for<TA>([&](auto TT) {
-            constexpr int tt = decltype(TT)::value, set = tt & 1;
-            static_for<NSLOT>([&](auto SL) {
-                constexpr int sl = decltype(SL)::value, s = sl >> 1, half = sl & 1, tau = s >> 2, r = s & 3;
-                if constexpr (half == 0) {
-                    tw_cur = tw_pre;
-                    if constexpr (s == 0) tw_cur.x *= c_half;
-                    if constexpr (4 * s + 3 > H1) {   // rows a' > h1 of S and D are not data: drop them
-                        const int keep_m = -(int)(4 * s + lg <= H1);
-                        tw_cur.x = __int_as_float(__float_as_int(tw_cur.x) & keep_m);
-                        tw_cur.y = __int_as_float(__float_as_int(tw_cur.y) & keep_m);
+            constexpr int tt = decltype(TT)::value;
+            uint4 epa[4];
+            uint2 epb[4];
+            static_for<4>([&](auto R) {   // bins of this tile's outputs, read under its MFMAs
+                constexpr int r = decltype(R)::value;
+                const uint32_t *e = ep + (((tt * 4 + r) * 64 + lane) << 3);
+                epa[r] = *(const uint4 *)e;
+                if constexpr (C2T > 2) epb[r] = *(const uint2 *)(e + 4);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            floatx4 acc[4][C2T];   // the sums A, B, C, E
+            static_for<KS2>([&](auto S) {
+                constexpr int s = decltype(S)::value, tau = s >> 2, r = s & 3;
+                static_for<C2T>([&](auto C) {
+                    constexpr int c = decltype(C)::value;
+                    if constexpr (s == 0) {
+                        mfma2_new(acc[0][c], t1c[tt][s], Yr[c][tau][r]);
+                        mfma2_new(acc[2][c], t1c[tt][s], Yi[c][tau][r]);
+                        mfma2_new(acc[1][c], t1s[tt][s], Yi[c][tau + TA][r]);
+                        mfma2_new(acc[3][c], t1s[tt][s], Yr[c][tau + TA][r]);
+                    } else {
+                        mfma2_acc(acc[0][c], t1c[tt][s], Yr[c][tau][r]);
+                        mfma2_acc(acc[2][c], t1c[tt][s], Yi[c][tau][r]);
+                        mfma2_acc(acc[1][c], t1s[tt][s], Yi[c][tau + TA][r]);
+                        mfma2_acc(acc[3][c], t1s[tt][s], Yr[c][tau + TA][r]);
                     }
+                });
+            });
+            mfma_drain();
 #pragma unroll
-                    for (int c = 0; c < C2T; ++c) {
-                        acc[set][0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw_cur.x, Yr[c][tau][r], s == 0 ? z4 : acc[set][0][c], 0, 0, 0);
-                        acc[set][2][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw_cur.x, Yi[c][tau][r], s == 0 ? z4 : acc[set][2][c], 0, 0, 0);
-                    }
-                    if constexpr (s + 1 < KS2) {
-                        const int nx = m1 + st1;
-                        m1 = nx >= N1 ? nx - N1 : nx;
-                        tw_pre = tw1[m1];
-                    } else if constexpr (tt + 1 < TA) {
-                        tile_start(tt + 1);
-                    }
-                } else {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int c = 0; c < C2T; ++c) {
-                        acc[set][1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw_cur.y, Yi[c][tau + TA][r], s == 0 ? z4 : acc[set][1][c], 0, 0, 0);
-                        acc[set][3][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(tw_cur.y, Yr[c][tau + TA][r], s == 0 ? z4 : acc[set][3][c], 0, 0, 0);
-                    }
-                }
-                if constexpr (tt > 0) {
-                    constexpr int lo = sl * NPIECE / NSLOT, hi = (sl + 1) * NPIECE / NSLOT;
-                    static_for<hi - lo>([&](auto J) { piece(ic<tt - 1>{}, ic<lo + decltype(J)::value>{}); });
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < C2T; ++c) after_drain(acc[i][c]);
+            __builtin_amdgcn_sched_barrier(0);
+            // arg-max work of the tile: two outputs per accumulator element
+            static_for<4>([&](auto R) {
+                static_for<C2T>([&](auto C) {
+                    constexpr int r = decltype(R)::value, c = decltype(C)::value;
+                    const float A = acc[0][c][r], B = acc[1][c][r], Cc = acc[2][c][r], E = acc[3][c][r];
+                    const float rp = A + B, rm = A - B, ip = Cc - E, im = Cc + E;
+                    float mp = rp * rp + ip * ip, mm = rm * rm + im * im;
+                    const unsigned tp = c == 0 ? epa[r].x : (c == 1 ? epa[r].z : (c == 2 ? epb[r].x : 0u));
+                    const unsigned tm = c == 0 ? epa[r].y : (c == 1 ? epa[r].w : (c == 2 ? epb[r].y : 0u));
+                    // outputs that must not compete although their value is not zero: known positions
+                    constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
+                    if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
+                    if constexpr (c == 0 || (tt == 0 && r == 0) || (xhere && P::XMINUS))
+                        mm = __builtin_unpredictable(tm & EP_UNUSED) ? 0.f : mm;
+                    best.mx = fmaxf(best.mx, fmaxf(mp, mm));
+                    top3_insert(best, (__float_as_uint(mp) & ~KEY_BIN) | tp);
+                    top3_insert(best, (__float_as_uint(mm) & ~KEY_BIN) | tm);
+                });
             });
         });
-        static_for<NPIECE>([&](auto Q) { piece(ic<TA - 1>{}, Q); });
-        // wave-wide merge of the per-lane top three
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned o1 = __shfl_xor(best.k1, d), o2 = __shfl_xor(best.k2, d), o3 = __shfl_xor(best.k3, d);
-            best.mx = fmaxf(best.mx, __shfl_xor(best.mx, d));
+        lap(ic<3>{});
+        // wave-wide merge of the per-lane top three: lane pairs, quads, eights and sixteens by
+        // DPP (each step merges two disjoint lane sets), the rest through LDS permutes
+        auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, float om) {
+            best.mx = fmaxf(best.mx, om);
             top3_insert(best, o1);
             top3_insert(best, o2);
             top3_insert(best, o3);
-        }
+        };
+#define WN_MERGE_DPP(CTRL)                                                                              \
+    merge_with(dpp_u<CTRL>(best.k1), dpp_u<CTRL>(best.k2), dpp_u<CTRL>(best.k3),                        \
+               __uint_as_float(dpp_u<CTRL>(__float_as_uint(best.mx))))
+        WN_MERGE_DPP(0xB1);    // quad_perm [1,0,3,2]
+        WN_MERGE_DPP(0x4E);    // quad_perm [2,3,0,1]
+        WN_MERGE_DPP(0x141);   // row_half_mirror
+        WN_MERGE_DPP(0x140);   // row_mirror
+#undef WN_MERGE_DPP
+#pragma unroll
+        for (int d = 16; d <= 32; d <<= 1)
+            merge_with(__shfl_xor(best.k1, d), __shfl_xor(best.k2, d), __shfl_xor(best.k3, d), __shfl_xor(best.mx, d));
         {
             const bool silent = best.mx <= 0.f;   // every bin is zero: np.argmax gives bin 0
             const float f1 = __uint_as_float(best.k1 & ~KEY_BIN), f2 = __uint_as_float(best.k2 & ~KEY_BIN),
@@ -476,12 +523,19 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             pend_w = w;
             pend = true;
         }
+        lap(ic<4>{});
         w = wn;
     }
     flush();
-    if ((dbg & 8) && blockIdx.x == 0 && threadIdx.x == 0) {   // diagnostic: shader clock = 100 MHz * [0]/[1]
-        out_bin[0] = (int)((__builtin_amdgcn_s_memtime() - dbg_t0) >> 8);
-        out_bin[1] = (int)((__builtin_amdgcn_s_memrealtime() - dbg_r0) >> 8);
+    if constexpr (PROF) {
+        // out_bin[0..4]: clocks/256 per phase (DMA wait, stage 1, stores + next DMA issue,
+        // stage 2 with its arg-max work, merge + decision); [7]: total clocks/256;
+        // [8]: 100 MHz ticks/256
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int i = 0; i < 7; ++i) out_bin[i] = (int)(prof[i] >> 8);
+            out_bin[7] = (int)((__builtin_amdgcn_s_memtime() - prof_c0) >> 8);
+            out_bin[8] = (int)((__builtin_amdgcn_s_memrealtime() - prof_r0) >> 8);
+        }
     }
 }
 
@@ -604,20 +658,30 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     typedef Plan<N1, N2> P;
     static bool attr = false;
     if (!attr) {
-        WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2>,
+        WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS));
+        WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS));
         attr = true;
     }
+    // WN_DETECT_PROFILE=1 (diagnostics, results are not usable): per-phase clock counts of wave 0
+    // in out_bin[0..8]
+    const bool prof = getenv("WN_DETECT_PROFILE") && atoi(getenv("WN_DETECT_PROFILE")) != 0;
     const long long total = n_streams * n_windows;
     long long blocks = (total + 3) / 4;
     if (blocks > ctx->num_cus) blocks = ctx->num_cus;
     // squared magnitudes are compared, through keys that drop up to 2^-11 of the value
     const double k = (1.0 - ctx->tie_band) * (1.0 - ctx->tie_band) / (1.0 + 1.0 / 2048.0) * (1.0 - 1e-6);
-    hipLaunchKernelGGL((detect_kernel<N1, N2>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
-                       (long long)audio_len, (long long)n_streams, (long long)stream_stride,
-                       (long long)first_sample, (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut,
-                       ctx->e1, ctx->e2, (float)k, d_cls, d_mag, d_bin,
-                       getenv("WN_DETECT_DEBUG") ? atoi(getenv("WN_DETECT_DEBUG")) : 0);
+    if (prof)
+        hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
+                           (long long)n_streams, (long long)stream_stride, (long long)first_sample,
+                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, d_cls, d_mag,
+                           d_bin);
+    else
+        hipLaunchKernelGGL((detect_kernel<N1, N2, false>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
+                           (long long)n_streams, (long long)stream_stride, (long long)first_sample,
+                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, d_cls, d_mag,
+                           d_bin);
     return wn_launch_check("detect_kernel");
 }
 
