@@ -170,6 +170,14 @@ def main():
         win_per_launch = sub * nwin
         flop = detect_flop_per_window(n1, n2) * win_per_launch
         achieved = flop / (det_ms * 1e-3) / 1e12
+        # HBM traffic of the detection launch from the committed PMC passes of this same command
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01c_pmc.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)["kernels"].get("detect_kernel<83, 85, false>", {})
+            if "hbm_bytes" in pmc:
+                traffic = pmc["hbm_bytes"] * win_per_launch / 4330000.0
         line = {
             "metric": "audio-seconds demodulated/sec", "value": value, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,7 +190,9 @@ def main():
             "frames_per_s": world * S * args.steps / elapsed,
             "roofline": {"bound": "mfma", "kernel": "detect_kernel<83,85> (+ float64 re-evaluation pass)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_source": "profiles/r01c_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + "
+                                           "WRITE_SIZE passes of this command, bytes per launch",
                          "flop_per_window": detect_flop_per_window(n1, n2), "windows_per_launch": win_per_launch,
                          "ms_per_launch": det_ms},
             "synth": {"bound": "hbm", "ms_per_launch": syn_ms,
