@@ -186,9 +186,9 @@ __device__ __forceinline__ void dma_group(const float *p, unsigned lds) {
 #undef WN_DMA_ASM
 }
 
-template <int CTRL>
+template <int CTRL, int ROWS>
 __device__ __forceinline__ unsigned dpp_u(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xF, false);
 }
 
 template <int N1, int N2, bool PROF>
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     unsigned pend_cls = 0;
     float pend_mag = 0.f;
     auto flush = [&]() {
-        if (pend && lane == 0) {
+        if (pend && lane == 63) {
             out_bin[pend_w] = pend_bin;
             out_cls[pend_w] = (uint16_t)pend_cls;
             out_mag[pend_w] = pend_mag;
@@ -491,25 +491,26 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             });
         });
         lap(ic<3>{});
-        // wave-wide merge of the per-lane top three: lane pairs, quads, eights and sixteens by
-        // DPP (each step merges two disjoint lane sets), the rest through LDS permutes
+        // wave-wide merge of the per-lane top three, all by DPP: lane pairs, quads, eights and
+        // sixteens merge two disjoint lane sets each and leave every lane of a row with the
+        // row's result; two row broadcasts then collect the four rows in the last row (the
+        // other rows merge with themselves and are not used).  Lane 63 decides and stores.
         auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, float om) {
             best.mx = fmaxf(best.mx, om);
             top3_insert(best, o1);
             top3_insert(best, o2);
             top3_insert(best, o3);
         };
-#define WN_MERGE_DPP(CTRL)                                                                              \
-    merge_with(dpp_u<CTRL>(best.k1), dpp_u<CTRL>(best.k2), dpp_u<CTRL>(best.k3),                        \
-               __uint_as_float(dpp_u<CTRL>(__float_as_uint(best.mx))))
-        WN_MERGE_DPP(0xB1);    // quad_perm [1,0,3,2]
-        WN_MERGE_DPP(0x4E);    // quad_perm [2,3,0,1]
-        WN_MERGE_DPP(0x141);   // row_half_mirror
-        WN_MERGE_DPP(0x140);   // row_mirror
+#define WN_MERGE_DPP(CTRL, ROWS)                                                                        \
+    merge_with(dpp_u<CTRL, ROWS>(best.k1), dpp_u<CTRL, ROWS>(best.k2), dpp_u<CTRL, ROWS>(best.k3),     \
+               __uint_as_float(dpp_u<CTRL, ROWS>(__float_as_uint(best.mx))))
+        WN_MERGE_DPP(0xB1, 0xF);    // quad_perm [1,0,3,2]
+        WN_MERGE_DPP(0x4E, 0xF);    // quad_perm [2,3,0,1]
+        WN_MERGE_DPP(0x141, 0xF);   // row_half_mirror
+        WN_MERGE_DPP(0x140, 0xF);   // row_mirror
+        WN_MERGE_DPP(0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+        WN_MERGE_DPP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
 #undef WN_MERGE_DPP
-#pragma unroll
-        for (int d = 16; d <= 32; d <<= 1)
-            merge_with(__shfl_xor(best.k1, d), __shfl_xor(best.k2, d), __shfl_xor(best.k3, d), __shfl_xor(best.mx, d));
         {
             const bool silent = best.mx <= 0.f;   // every bin is zero: np.argmax gives bin 0
             const float f1 = __uint_as_float(best.k1 & ~KEY_BIN), f2 = __uint_as_float(best.k2 & ~KEY_BIN),
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
     __shared__ double red[4][4];
     __shared__ double best_m[4];
     __shared__ int best_b[4];
+    __shared__ unsigned long long flagged[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long total = n_streams * n_windows;
     bool table_ready = false;
@@ -578,11 +580,15 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
             table_ready = true;
             __syncthreads();
         }
-        const int cnt = (int)((total - base) < 256 ? (total - base) : 256);
-        for (int j = 0; j < cnt; ++j) {
-            const long long wi = base + j;
+        // flagged windows of this chunk, one bit per thread
+        const unsigned long long bal = __ballot(fl != 0);
+        __syncthreads();
+        if (lane == 0) flagged[wave] = bal;
+        __syncthreads();
+        for (int fw = 0; fw < 4; ++fw)
+        for (unsigned long long mask = flagged[fw]; mask; mask &= mask - 1) {
+            const long long wi = base + 64 * fw + __ffsll((long long)mask) - 1;
             const int f = bin[wi];  // same address in every thread
-            if (!(f & FLAG_MASK)) continue;
             const long long s = wi / n_windows;
             const float *x = audio + s * stream_stride + first_sample + (wi - s * n_windows) * (long long)N;
             int rb;
