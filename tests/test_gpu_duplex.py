@@ -1,0 +1,131 @@
+"""Two endpoints on one simulated air, through the HIP path: the reference's two-machine
+transfers (c1_communication.py:5-327) must end the way the reference's own run of the same
+scenario ended (tests/golden/duplex_golden.json, written by make_golden_duplex.py): same
+return values, same final clocks, same samples played, and every listen call consuming the
+same number of windows and hearing the same bytes."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def duplex():
+    with open(os.path.join(HERE, "golden", "duplex_golden.json")) as f:
+        return json.load(f)
+
+
+def run_endpoints(roles, ruido=None):
+    """roles: {name: callable}.  One thread and one endpoint per role; listen calls are logged
+    where c1_communication looks its functions up."""
+    from wavenet_amd.dispositivo_wavenet import c1_communication as cc
+    from wavenet_amd.dispositivo_wavenet import c1_shared as cs
+    from wavenet_amd.dispositivo_wavenet.canal import Aire
+
+    cs.modem()          # build the device tables before the threads start
+    aire = Aire(ruido=ruido)
+    out, errores = {}, []
+    listen0, ping0 = cc.escuchar_y_retornar_trama, cc.escuchar_ping
+    registro = threading.local()
+
+    def listen(timeout):
+        c, t0 = cs.canal(), cs.canal().leido
+        try:
+            tr = listen0(timeout)
+            registro.calls.append({"kind": "frame", "windows": (c.leido - t0) // 7055,
+                                   "bytes": bytes(tr.bytes_trama).hex(), "error": None})
+            return tr
+        except ValueError as e:
+            registro.calls.append({"kind": "frame", "windows": (c.leido - t0) // 7055, "bytes": None, "error": str(e)})
+            raise
+
+    def ping(timeout):
+        c, t0 = cs.canal(), cs.canal().leido
+        r = ping0(timeout)
+        registro.calls.append({"kind": "ping", "windows": (c.leido - t0) // 7055, "result": bool(r)})
+        return r
+
+    extremos = {nombre: aire.extremo(nombre) for nombre in roles}
+
+    def cuerpo(nombre, fn):
+        ext = extremos[nombre]
+        cs.usar_canal(ext)
+        registro.calls = []
+        try:
+            res = fn()
+            out[nombre] = {"result": res, "clock": ext.leido, "played": ext.emitido, "calls": registro.calls}
+        except BaseException as e:   # surfaced by the main thread
+            errores.append((nombre, repr(e)))
+        finally:
+            ext.terminar()
+
+    cc.escuchar_y_retornar_trama, cc.escuchar_ping = listen, ping
+    try:
+        hilos = [threading.Thread(target=cuerpo, args=(n, f)) for n, f in roles.items()]
+        for h in hilos:
+            h.start()
+        for h in hilos:
+            h.join(timeout=280)
+        assert not any(h.is_alive() for h in hilos), "an endpoint did not finish"
+    finally:
+        cc.escuchar_y_retornar_trama, cc.escuchar_ping = listen0, ping0
+    assert not errores, errores
+    return out
+
+
+def ruido_de(s):
+    if s["sigma"] <= 0:
+        return None
+    return s["sigma"] * np.random.default_rng(s["seed"]).standard_normal(int(s["noise_seconds"] * 44100))
+
+
+def comparar(out, s):
+    for nombre in out:
+        esperado = s[nombre]
+        assert out[nombre]["result"] == esperado["result"], nombre
+        assert out[nombre]["calls"] == esperado["calls"], nombre
+        assert out[nombre]["played"] == esperado["played"], nombre
+        assert out[nombre]["clock"] == esperado["clock"], nombre
+
+
+@pytest.mark.parametrize("nombre", ["string_short_clean", "string_prueba_noise", "string_no_receiver"])
+def test_string_transfer_like_the_reference(duplex, nombre):
+    from wavenet_amd.dispositivo_wavenet import c1_communication as cc
+
+    s = next(x for x in duplex["scenarios"] if x["name"] == nombre)
+    a, b = duplex["mac_sender"], duplex["mac_receiver"]
+    roles = {"tx": lambda: cc.enviar_string_por_sonido(s["message"], a, b)}
+    if "rx" in s:
+        roles["rx"] = lambda: cc.escuchar_string(b)
+    comparar(run_endpoints(roles, ruido_de(s)), s)
+
+
+def test_file_transfer_like_the_reference(duplex, tmp_path, monkeypatch):
+    from wavenet_amd.dispositivo_wavenet import c1_communication as cc
+
+    s = next(x for x in duplex["scenarios"] if x["name"] == "file_two_frames")
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / s["file_name"]).write_bytes(bytes.fromhex(s["file_bytes"]))
+    a, b = duplex["mac_sender"], duplex["mac_receiver"]
+    out = run_endpoints({"tx": lambda: cc.enviar_archivo_por_sonido(s["file_name"], a, b),
+                         "rx": lambda: cc.escuchar_archivo(b)})
+    comparar(out, s)
+    assert (tmp_path / ("new_" + s["file_name"])).read_bytes() == bytes.fromhex(s["received_bytes"])
+
+
+def test_device_objects_talk_to_each_other(duplex):
+    """DispositivoWaveNet.send / listen (dispositivo_wavenet.py:24-52) between two endpoints."""
+    from wavenet_amd.dispositivo_wavenet.dispositivo_wavenet import DispositivoWaveNet
+
+    a, b = duplex["mac_sender"], duplex["mac_receiver"]
+    out = run_endpoints({"tx": lambda: DispositivoWaveNet(a, b).send("hola mundo"),
+                         "rx": lambda: DispositivoWaveNet(b).listen()})
+    assert out["rx"]["result"] == "hola mundo" and out["tx"]["result"] is None
+    s = next(x for x in duplex["scenarios"] if x["name"] == "string_short_clean")
+    assert out["rx"]["clock"] == s["rx"]["clock"] and out["tx"]["clock"] == s["tx"]["clock"]

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import argparse
 import logging
+import threading
 
 import numpy as np
 import torch
@@ -58,27 +59,31 @@ _MENSAJES = {
 # Device state: one modem per scheme, one current channel
 # ------------------------------------------------------------------------------------------
 _modems: dict = {}
-_canal: CanalSintetico | None = None
+_hilo = threading.local()      # the current channel is per thread: one endpoint per thread
+
+
+_modems_lock = threading.Lock()
 
 
 def modem(esquema: str = "B") -> M.Modem:
-    if esquema not in _modems:
-        _modems[esquema] = M.Modem(M.esquema_b() if esquema == "B" else M.esquema_a())
-    return _modems[esquema]
+    with _modems_lock:
+        if esquema not in _modems:
+            _modems[esquema] = M.Modem(M.esquema_b() if esquema == "B" else M.esquema_a())
+        return _modems[esquema]
 
 
-def usar_canal(canal: CanalSintetico | None) -> CanalSintetico | None:
-    """Install the synthetic audio device every play/rec of this module goes to."""
-    global _canal
-    previo, _canal = _canal, canal
+def usar_canal(canal):
+    """Install the synthetic audio device every play/rec of this module goes to, for the
+    calling thread (a `CanalSintetico`, or an `ExtremoAire` of a shared `Aire`)."""
+    previo = getattr(_hilo, "canal", None)
+    _hilo.canal = canal
     return previo
 
 
-def canal() -> CanalSintetico:
-    global _canal
-    if _canal is None:
-        _canal = CanalSintetico(M.esquema_b())
-    return _canal
+def canal():
+    if getattr(_hilo, "canal", None) is None:
+        _hilo.canal = CanalSintetico(M.esquema_b())
+    return _hilo.canal
 
 
 def _dev(data: bytes, ancho: int) -> torch.Tensor:
@@ -242,19 +247,53 @@ def _ventanas_disponibles(c: CanalSintetico, cuantas: int):
     return c.audio, c.leido, cuantas
 
 
+def _escuchar_trama_por_tramos(c, m, tw):
+    """The listen loop on a shared air: windows are taken as they become certain, the state
+    machine is re-run over everything heard so far with one extra empty window appended, and
+    the call is over once the machine stops without touching that extra window."""
+    n = c.esquema.win_n
+    base, k = c.leido, 0
+    todas = torch.empty((1, 0), dtype=torch.int16, device=m.device)
+    vacia = torch.full((1, 1), L.CLS_NONE, dtype=torch.int16, device=m.device)
+    while True:
+        nuevas = c.esperar_ventanas(base + k * n, 2 * tw - k)
+        audio = c.audio
+        cls, _, _ = m.detect(audio, 1, audio.numel(), nuevas, base + k * n)
+        k += nuevas
+        todas = torch.cat([todas, cls], dim=1)
+        by, lens, _, end, _, _ = m.slice(torch.cat([todas, vacia], dim=1).contiguous(), tw, 1, 288)
+        usados = int(end[0, 0])
+        if usados <= k or k >= 2 * tw:
+            return by, lens, min(usados, k)
+        c.confirmar(base + k * n)
+
+
 def escuchar_y_retornar_trama(timeout):
     """Listens for one frame for `timeout` seconds of channel time; the clock restarts at
     the ping (reference c1_shared.py:301-355).  Returns the Trama or raises ValueError."""
     c, m = canal(), modem()
     tw = m.timeout_windows(timeout)
-    audio, desde, nwin = _ventanas_disponibles(c, 2 * tw)
-    cls, _, _ = m.detect(audio, 1, audio.numel(), nwin, desde)
-    by, lens, _, end, _, _ = m.slice(cls, tw, 1, 288)
-    usados = int(end[0, 0])
+    if c.incremental:
+        by, lens, usados = _escuchar_trama_por_tramos(c, m, tw)
+    else:
+        audio, desde, nwin = _ventanas_disponibles(c, 2 * tw)
+        cls, _, _ = m.detect(audio, 1, audio.numel(), nwin, desde)
+        by, lens, _, end, _, _ = m.slice(cls, tw, 1, 288)
+        usados = int(end[0, 0])
     c.leido += usados * c.esquema.win_n
     recibidos = by[0, 0, :int(lens[0, 0])].cpu().numpy().tolist()
     logging.info(f"{recibidos}")
     return Trama(bytes_trama=recibidos)
+
+
+def _pings(m, audio, desde, nwin):
+    """Per window: does a ping tone dominate it?"""
+    _, _, verdict = m.sync_scan(audio, 1, audio.numel(), nwin, desde)
+    v = verdict[0].cpu().numpy()
+    if (v == 2).any():       # undecided windows: only the spectrum can tell
+        cls, _, _ = m.detect(audio, 1, audio.numel(), nwin, desde)
+        return (cls[0].cpu().numpy().astype(np.uint16) & L.CLS_PING) != 0
+    return v == 1
 
 
 def escuchar_ping(timeout):
@@ -262,34 +301,34 @@ def escuchar_ping(timeout):
     (reference c1_shared.py:357-384)."""
     c, m = canal(), modem()
     tw = m.timeout_windows(timeout)
-    audio, desde, nwin = _ventanas_disponibles(c, tw)
-    _, _, verdict = m.sync_scan(audio, 1, audio.numel(), nwin, desde)
-    v = verdict[0].cpu().numpy()
-    if (v == 2).any():       # undecided windows: only the spectrum can tell
-        cls, _, _ = m.detect(audio, 1, audio.numel(), nwin, desde)
-        es_ping = (cls[0].cpu().numpy().astype(np.uint16) & L.CLS_PING) != 0
-    else:
-        es_ping = v == 1
-    idx = np.flatnonzero(es_ping)
-    if len(idx):
-        c.leido += (int(idx[0]) + 1) * c.esquema.win_n
-        logging.info("Escuche el ping")
-        return True
-    c.leido += nwin * c.esquema.win_n
+    n = c.esquema.win_n
+    base, k = c.leido, 0
+    while k < tw:
+        if c.incremental:
+            nuevas = c.esperar_ventanas(base + k * n, tw - k)
+            audio = c.audio
+        else:
+            audio, _, nuevas = _ventanas_disponibles(c, tw)
+        idx = np.flatnonzero(_pings(m, audio, base + k * n, nuevas))
+        if len(idx):
+            c.leido = base + (k + int(idx[0]) + 1) * n
+            logging.info("Escuche el ping")
+            return True
+        k += nuevas
+        if c.incremental and k < tw:
+            c.confirmar(base + k * n)
+    c.leido = base + tw * n
     logging.info("Timeout alcanzado. Terminando escucha.")
     return False
 
 
 def _tono(freq, n):
-    """Appends n samples of a `freq` Hz tone to the channel (one-segment schedule)."""
+    """Plays n samples of a `freq` Hz tone (one-segment schedule)."""
     c, m = canal(), modem()
     dev = m.device
     lay = (torch.tensor([[0, n]], dtype=torch.int32, device=dev), torch.tensor([[freq]], dtype=torch.int16, device=dev),
            torch.tensor([1], dtype=torch.int32, device=dev), None)
-    pos = c.posicion_escritura()
-    c.reservar(pos + n)
-    m.synth(lay, torch.tensor([pos], dtype=torch.int64, device=dev), c.audio, M.pad4(n))
-    c.avanzar_escritura(n)
+    c.emitir(m, lay, n)
 
 
 def transmite_freq(freq, duration=BYTE_DURATION):
@@ -313,11 +352,7 @@ def emitir_trama(trama):
     frames = _dev(raw, _ancho(len(raw)))
     lens = torch.tensor([len(raw)], dtype=torch.int32, device=m.device)
     lay = m.layout(frames, lens, L.EMIT_LIVE)
-    n = M.host_frame_samples(m.esquema, raw, L.EMIT_LIVE)
-    pos = c.posicion_escritura()
-    c.reservar(pos + n)
-    m.synth(lay, torch.tensor([pos], dtype=torch.int64, device=m.device), c.audio, M.pad4(n))
-    c.avanzar_escritura(n)
+    c.emitir(m, lay, M.host_frame_samples(m.esquema, raw, L.EMIT_LIVE))
     logging.info("Trama transmitida.")
 
 
