@@ -213,6 +213,37 @@ G["scenarios"].append({"name": "file_two_frames", "kind": "file", "file_name": "
                        "noise_seconds": 0, **out})
 print("file transfer:", out["tx"]["result"], out["rx"]["result"], got == data)
 
+# 5. the WAV files of mode 1 (guardar_archivo_en_tramas_wav, c1_shared.py:440-525), read back as a
+#    capture (int16 / 32768, 0.5 s of silence between files) and heard by the reference's listener
+wavs = {}
+cs.write = lambda name, rate, data_: wavs.__setitem__(os.path.basename(name), (rate, np.array(data_)))
+with tempfile.TemporaryDirectory() as tmp:
+    src = os.path.join(tmp, "prueba.txt")
+    with open(src, "wb") as f:
+        f.write(text.encode())
+    cs.guardar_archivo_en_tramas_wav(src, MAC_A, MAC_B)
+names = sorted(wavs)
+assert all(r == SR and d.dtype == np.int16 for r, d in wavs.values())
+gap = np.zeros(SR // 2)
+cap = np.concatenate([np.concatenate([gap, wavs[n][1].astype(np.float64) / 32768.0]) for n in names] + [gap])
+
+
+def hear_all():
+    _play(cap)          # put the capture on the air, then rewind this endpoint's clock and listen to it
+    me().t = 0
+    for _ in range(len(names) + 1):
+        try:
+            cc.escuchar_y_retornar_trama(cs.TIME_TO_SAY_128_BYTES)
+        except ValueError:
+            pass
+    return True
+
+
+out = run({"rx": hear_all})
+G["wav_listen"] = {"files": names, "n_samples": [int(len(wavs[n][1])) for n in names], "gap": len(gap),
+                   "timeout": cs.TIME_TO_SAY_128_BYTES, "calls": out["rx"]["calls"], "clock": out["rx"]["clock"]}
+print("wav listen:", [(c["windows"], c["error"], None if c["bytes"] is None else len(c["bytes"]) // 2) for c in out["rx"]["calls"]])
+
 path = os.path.join(HERE, "duplex_golden.json")
 with open(path, "w") as f:
     json.dump(G, f, separators=(",", ":"))

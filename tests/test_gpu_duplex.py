@@ -129,3 +129,62 @@ def test_device_objects_talk_to_each_other(duplex):
     assert out["rx"]["result"] == "hola mundo" and out["tx"]["result"] is None
     s = next(x for x in duplex["scenarios"] if x["name"] == "string_short_clean")
     assert out["rx"]["clock"] == s["rx"]["clock"] and out["tx"]["clock"] == s["tx"]["clock"]
+
+
+def test_wav_files_read_back_like_the_reference_hears_them(duplex, tmp_path, capsys):
+    """Mode 1 of the command line writes one WAV per frame (c1_shared.py:440-525); read back
+    as a capture, the listener must hear what the reference's listener hears in the
+    reference's own files: same bytes, same windows consumed, same final timeout."""
+    from scipy.io.wavfile import read
+    from wavenet_amd.dispositivo_wavenet import c1_shared as cs
+    from wavenet_amd.dispositivo_wavenet import dispositivo_wavenet as dw
+    from wavenet_amd.dispositivo_wavenet.canal import CanalSintetico
+
+    g = duplex["wav_listen"]
+    texto = next(x for x in duplex["scenarios"] if x["name"] == "string_prueba_noise")["message"]
+    src = tmp_path / "prueba.txt"
+    src.write_bytes(texto.encode())
+    dw.main(["-a", str(src), "-b", duplex["mac_sender"], "-c", duplex["mac_receiver"], "-d", "1"])
+    rutas = [str(tmp_path / n) for n in g["files"]]
+    for ruta, n in zip(rutas, g["n_samples"]):
+        rate, data = read(ruta)
+        assert rate == 44100 and data.dtype == np.int16 and len(data) == n
+    cs.usar_canal(CanalSintetico())
+    try:
+        cs.cargar_wavs_en_canal(rutas, g["gap"] / 44100)
+        c = cs.canal()
+        for esperado in g["calls"]:
+            t0 = c.leido
+            try:
+                tr = cs.escuchar_y_retornar_trama(g["timeout"])
+                oido, error = bytes(tr.bytes_trama).hex(), None
+            except ValueError as e:
+                oido, error = None, str(e)
+            assert (oido, error, (c.leido - t0) // 7055) == (esperado["bytes"], esperado["error"], esperado["windows"])
+        assert c.leido == g["clock"]
+        # mode 2 of the command line on the first file alone
+        capsys.readouterr()
+        dw.main(["-a", "x", "-b", duplex["mac_receiver"], "-d", "2", "-w", rutas[0]])
+        assert "No se escuho" not in capsys.readouterr().out
+        dw.main(["-a", "x", "-b", duplex["mac_receiver"], "-d", "2"])     # nothing left to hear
+        assert "No se escuho ninguna trama" in capsys.readouterr().out
+    finally:
+        cs.usar_canal(None)
+
+
+def test_layer2_packet_text_survives_the_sound_link(duplex):
+    """What SoundProtocol does with a packet (WaveNetProtocols.py:295-329): the sender hands
+    `Packet.form()` to DispositivoWaveNet(mac, dest).send(text, timeout=180), the listener
+    takes DispositivoWaveNet(mac, "").listen(timeout=180, init_timeout=40) and parses the
+    text.  The packet is the one of the reference's manual sound tests
+    (WaveNetCore/tests/test_sound_protocol_send.py:8); its text is restated here from
+    Packet.form (WaveNetPacketeering.py:36-49), not produced by running the reference."""
+    from wavenet_amd.dispositivo_wavenet.dispositivo_wavenet import DispositivoWaveNet
+
+    a, b = "0:0:0:0:0:0", "1:1:1:1:1:1"
+    campos = {"enc": False, "src": 1, "dest": 2, "mtype": "msg", "body": "ahu, ahua", "timestamp": "nope"}
+    texto = json.dumps(campos)
+    out = run_endpoints({"tx": lambda: DispositivoWaveNet(a, b).send(texto, timeout=60 * 3),
+                         "rx": lambda: DispositivoWaveNet(b, "").listen(timeout=60 * 3, init_timeout=40)})
+    assert out["rx"]["result"] == texto
+    assert json.loads(out["rx"]["result"]) == campos

@@ -376,6 +376,32 @@ def guardar_trama_como_wav(trama, nombre_archivo):
     logging.info(f"Trama guardada como archivo WAV: {nombre_archivo}")
 
 
+def leer_wav(nombre_archivo) -> np.ndarray:
+    """The samples of a WAV file as a capture for the listener: int16 scaled by 1/32768,
+    floating-point files as they are, first channel only.  The reference only writes WAV
+    files (c1_shared.py:440-471); this is the way back in."""
+    from scipy.io.wavfile import read
+    rate, data = read(nombre_archivo)
+    if rate != SAMPLE_RATE:
+        raise ValueError(f"{nombre_archivo}: {rate} Hz, se esperaban {SAMPLE_RATE}")
+    data = np.asarray(data)
+    if data.ndim > 1:
+        data = data[:, 0]
+    if np.issubdtype(data.dtype, np.integer):
+        return data.astype(np.float32) / float(1 << (8 * data.dtype.itemsize - 1))
+    return data.astype(np.float32)
+
+
+def cargar_wavs_en_canal(nombres, silencio=0.5):
+    """Makes the listed WAV files, `silencio` seconds of silence before each and after the
+    last, the capture of the current channel."""
+    hueco = np.zeros(int(silencio * SAMPLE_RATE), dtype=np.float32)
+    partes = []
+    for nombre in nombres:
+        partes += [hueco, leer_wav(nombre)]
+    canal().cargar(np.concatenate(partes + [hueco]))
+
+
 def _tramas_desde_bytes(data: bytes, mac_origen_str, mac_destino_str):
     org, dst = mac_str_to_bytes(mac_origen_str), mac_str_to_bytes(mac_destino_str)
     return [crear_trama(VERSION, org, dst, TIPO_TRAMA_ARCHIVO, data[i:i + 107]) for i in range(0, len(data), 107)]
