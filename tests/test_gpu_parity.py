@@ -282,6 +282,29 @@ def test_detect_noise_only_and_offsets(mb, golden):
         assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
 
 
+@pytest.mark.parametrize("scheme", ["B", "A"])
+def test_detect_every_bin(mb, ma, golden, scheme):
+    """One window per bin k of [0, N/2): a tone on the centre of bin k with a weaker one on
+    another bin.  Exercises every entry of the kernel's output-to-bin map (both halves of
+    every sum pair, the self-mirrored rows and columns, the excluded top bin)."""
+    m, n, lut = (mb, 7055, golden["classes_b_7055"]) if scheme == "B" else (ma, 2205, golden["classes_a_2205"])
+    lut = np.array(lut, dtype=np.uint16)
+    t = np.arange(n)
+    rng = np.random.default_rng(5)
+    wins = []
+    for k in range(n // 2):
+        k2 = (k + 1 + int(rng.integers(0, n // 2 - 2))) % (n // 2)
+        w = 0.4 * np.cos(2 * np.pi * k * t / n + rng.uniform(0, 6.28)) + 0.1 * np.cos(2 * np.pi * k2 * t / n + 0.7)
+        wins.append(w.astype(np.float32))
+    x32 = np.concatenate(wins)
+    cls = check_detect(m, x32, n, lut)
+    kbin = m.detect(dev(np.pad(x32, (0, 4))[:M.pad4(len(x32))]), 1, M.pad4(len(x32)), n // 2)[2].cpu().numpy()[0]
+    assert kbin.tolist() == list(range(n // 2))
+    # the bin just above the searched range must never win: put all the energy there
+    top = (0.4 * np.cos(2 * np.pi * (n // 2) * t / n) + 0.01 * np.cos(2 * np.pi * 7 * t / n)).astype(np.float32)
+    check_detect(m, top, n, lut)
+
+
 def test_detect_refinement_paths_forced(golden):
     """Raise the tie band so that the float64 re-evaluation runs on ordinary windows: both
     the two-bin and the whole-spectrum path must reproduce the oracle."""
