@@ -161,6 +161,33 @@ def test_synth_live_matches_reference_audio(mb, golden):
     assert np.allclose(audio[0, t["idx"][:16]], t["samples"][:16], rtol=0, atol=6e-8)
 
 
+@pytest.mark.parametrize("plan", ["some_tones_tabulated", "no_tone_tabulated"])
+def test_synth_tones_with_long_periods(plan):
+    """A tone plan whose byte tones repeat only after tens of thousands of samples (no period
+    table for them) and, in the second case, whose separator, ping and EOF tones do not
+    either: the sample-by-sample paths must give the same correctly rounded samples."""
+    import dataclasses
+    extra = dict(base_freq=351, freq_step=71) if plan == "some_tones_tabulated" else \
+        dict(base_freq=351, freq_step=71, sep_freq=201, ping_freq=251, eof_freq=301)
+    esq = dataclasses.replace(M.esquema_b(), **extra)
+    sch = dataclasses.replace(SB, **extra)
+    m = M.Modem(esq)
+    frames = [mo.build_frame(1, MAC_O, MAC_D, 3, bytes([0, 255, 3, 3, 17, 200])), mo.build_frame(1, MAC_D, MAC_O, 1, b"")]
+    buf, lens = rows_from(frames, 32)
+    stride = M.pad4(max(len(mo.emit_frame(f, sch)) for f in frames) + 9)
+    audio, n_samples = m.encode_streams(dev(buf), dev(lens), stride)
+    audio = audio.cpu().numpy()
+    for i, f in enumerate(frames):
+        ref = mo.emit_frame(f, sch)
+        assert int(n_samples[i]) == len(ref)
+        got = audio[i, :len(ref)].astype(np.float64)
+        half_ulp = 0.5 * np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+        assert np.all(np.abs(got - ref) <= half_ulp * 1.0001 + 5e-11)
+        assert not audio[i, len(ref):].any()
+    w, n = m.encode_streams(dev(buf), dev(lens), stride, variant=L.EMIT_WAV, dtype=torch.int16)
+    assert np.array_equal(w.cpu().numpy()[0, :int(n[0])], mo.wav_int16(frames[0], sch))
+
+
 def test_synth_sample_counts_with_repeats(mb, golden):
     frames = [bytes.fromhex(c["frame"]) for c in golden["sample_counts_b"]]
     buf, lens = rows_from(frames, 128)

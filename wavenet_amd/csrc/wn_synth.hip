@@ -215,6 +215,147 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(const int32_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------
+// Synthesis from period tables
+// ---------------------------------------------------------------------------------------
+#define SYN_MAX_TONES 320
+
+template <typename T>
+__global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
+    const int32_t *__restrict__ seg_start, const uint16_t *__restrict__ seg_freq, const int32_t *__restrict__ n_segs,
+    int seg_cap, long long n_frames, int parts, int part_len, const long long *__restrict__ dst_off,
+    const long long *__restrict__ fill_to, T *__restrict__ audio, long long audio_len,
+    const T *__restrict__ g_tab, int quarter, const wn_tone *__restrict__ g_tones, int n_tones,
+    const T *__restrict__ g_per) {
+    __shared__ int32_t s_start[SYN_MAX_SEGS + 1];
+    __shared__ uint16_t s_freq[SYN_MAX_SEGS];
+    __shared__ uint16_t s_tone[SYN_MAX_SEGS];   // index into tones, 0xFFFF = not tabulated
+    __shared__ wn_tone tones[SYN_MAX_TONES];
+    for (int i = threadIdx.x; i < n_tones; i += SYN_BLOCK) tones[i] = g_tones[i];
+    const int sr = 4 * quarter;
+    const float inv_sr = 1.0f / (float)sr;
+    typedef typename Vec4<T>::type V4;
+
+    const long long n_items = n_frames * parts;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const long long f = item / parts;
+        const int part = (int)(item - f * parts);
+        __syncthreads();  // descriptors ready / previous item's segment table no longer read
+        const int ns = n_segs[f];
+        for (int i = threadIdx.x; i <= ns; i += SYN_BLOCK) s_start[i] = seg_start[f * (long long)(seg_cap + 1) + i];
+        for (int i = threadIdx.x; i < ns; i += SYN_BLOCK) {
+            const int fq = seg_freq[f * (long long)seg_cap + i];
+            int lo = 0, hi = n_tones;            // first descriptor with freq >= fq
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (tones[mid].freq < fq) lo = mid + 1; else hi = mid;
+            }
+            s_freq[i] = (uint16_t)fq;
+            s_tone[i] = (lo < n_tones && tones[lo].freq == fq) ? (uint16_t)lo : (uint16_t)0xFFFF;
+        }
+        __syncthreads();
+        const int total = s_start[ns];
+        long long end = fill_to ? fill_to[f] : (long long)total;
+        if (end < total) end = total;
+        const long long base = dst_off[f];
+        if (base < 0) continue;                              // never write outside the buffer
+        if (base + end > audio_len) end = audio_len - base;
+        const long long p0l = (long long)part * part_len;
+        long long p1l = p0l + part_len;
+        if (p1l > end) p1l = end;
+        if (p0l >= p1l) continue;
+        const int p0 = (int)p0l, p1 = (int)p1l;
+        const bool vec_ok = (((base + p0) & 3) == 0);
+
+        // first segment of this part: binary search (same result in every thread)
+        int sg = ns;
+        if (p0 < total) {
+            int lo = 0, hi = ns - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_start[mid] <= p0) lo = mid; else hi = mid - 1;
+            }
+            sg = lo;
+        }
+        // this thread's current segment [lo, hi), kept in registers, and where in the tone's
+        // period its next vector starts (j), advanced by the thread's stride modulo the period
+        int lo = sg < ns ? s_start[sg] : total;
+        int hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
+        int fq = 0, period = 0, jstep = 0, j = 0;
+        const T *per = nullptr;      // copy 0 of the current tone, or null
+        int stride = 0;
+        bool fresh = true;           // segment changed: j must be computed, not advanced
+        for (int p = p0 + 4 * (int)threadIdx.x; p < p1; p += 4 * SYN_BLOCK) {
+            while (p >= hi) {
+                ++sg;
+                lo = hi;
+                hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
+                fresh = true;
+            }
+            T v[4];
+            if (sg >= ns) {                    // past the frame: zero fill
+                v[0] = v[1] = v[2] = v[3] = (T)0;
+            } else {
+                if (fresh) {
+                    fresh = false;
+                    fq = s_freq[sg];
+                    const int ti = s_tone[sg];
+                    if (ti != 0xFFFF) {
+                        const wn_tone t = tones[ti];
+                        period = t.period;
+                        stride = t.stride;
+                        per = g_per + t.offset;
+                        j = (int)((unsigned)(p - lo) % (unsigned)period);
+                        jstep = (4 * SYN_BLOCK) % period;
+                    } else {
+                        per = nullptr;
+                    }
+                } else if (per) {
+                    j += jstep;
+                    j = j >= period ? j - period : j;
+                }
+                if (per && p + 3 < hi) {       // four samples of one tabulated tone: one aligned load
+                    const int r = j & 3;
+                    const V4 o = *(const V4 *)(per + r * stride + (j - r));
+                    v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
+                } else {                       // another frequency, or a segment boundary inside the vector
+                    int sl = sg, ll = lo, hl = hi, fl = fq;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int pe = p + e;
+                        while (pe >= hl) {
+                            ++sl;
+                            ll = hl;
+                            hl = sl < ns ? s_start[sl + 1] : 0x7fffffff;
+                            fl = sl < ns ? s_freq[sl] : 0;
+                        }
+                        if (sl < ns) {
+                            const int m = mod_sr((unsigned)fl * (unsigned)(pe - ll), sr, inv_sr);
+                            const int half = 2 * quarter;
+                            const bool neg = m >= half;
+                            const int m2 = neg ? m - half : m;
+                            const T t = g_tab[m2 > quarter ? half - m2 : m2];
+                            v[e] = neg ? (T)(-t) : t;
+                        } else {
+                            v[e] = (T)0;
+                        }
+                    }
+                }
+            }
+            T *dst = audio + base + p;
+            if (vec_ok && p + 4 <= p1) {
+                V4 o;
+                o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+                *(V4 *)dst = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (p + e < p1) dst[e] = v[e];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Channel noise: sample i gets sigma * z(seed, i), z from splitmix64 bits by Box-Muller.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -269,19 +410,21 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     WN_REQUIRE(n == 0 || (d_seg_start && d_seg_freq && d_n_segs && d_dst_off && d_audio), "null device pointer");
     if (n == 0) return WN_OK;
     const size_t esz = fmt == WN_FMT_F32 ? 4 : 2;
+    const bool tabulated = ctx->n_tones > 0 && ctx->n_tones <= SYN_MAX_TONES;
     const size_t tab_entries = ((size_t)ctx->quarter + 1 + 31) & ~(size_t)31;
-    const size_t lds = (SYN_MAX_SEGS + 1) * 4 + SYN_MAX_SEGS * 2 + 8 + tab_entries * esz;
+    const size_t lds = tabulated ? 0 : (SYN_MAX_SEGS + 1) * 4 + SYN_MAX_SEGS * 2 + 8 + tab_entries * esz;
     WN_REQUIRE(lds <= 150 * 1024, "sample_rate too large for the LDS sine table");
-    // one launch = as many workgroups as stay resident (LDS-limited), each looping over
-    // (frame, part) items; parts of a frame balance the load when there are few frames
-    int per_cu = (int)((160 * 1024) / lds);
+    // one launch = as many workgroups as stay resident, each looping over (frame, part)
+    // items; parts of a frame balance the load when there are few frames
+    int per_cu = tabulated ? 2 : (int)((160 * 1024) / lds);
     if (per_cu > 2048 / SYN_BLOCK) per_cu = 2048 / SYN_BLOCK;
     if (per_cu < 1) per_cu = 1;
     const long long resident = (long long)ctx->num_cus * per_cu;
-    // Parts of 96 Ki samples (384 KB): consecutive workgroups then write consecutive pieces
-    // of HBM, which the memory system serves much better than one far-apart stream per
-    // workgroup (measured 5.0 vs 3.9 TB/s).  WN_SYNTH_PART overrides the size for tuning.
-    long long part_want = 98304;
+    // Parts of 48 Ki samples (192 KB) and two workgroups per CU: consecutive workgroups then
+    // write consecutive pieces of HBM and the region being written at any time stays around
+    // 100 MB, which the memory system serves best (measured 4.0-5.1 TB/s over part sizes of
+    // 16 KB-1.5 MB and 1-4 workgroups per CU).  WN_SYNTH_PART overrides the size for tuning.
+    long long part_want = tabulated ? 49152 : 98304;
     if (const char *e = getenv("WN_SYNTH_PART")) {
         const long long v = atoll(e);
         if (v >= 4096) part_want = v;
@@ -294,6 +437,21 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     const long long items = n * parts;
     const long long blocks = items < resident ? items : resident;
     hipStream_t st = (hipStream_t)stream;
+    if (tabulated) {
+        if (fmt == WN_FMT_F32)
+            hipLaunchKernelGGL(synth_period_kernel<float>, dim3((unsigned)blocks), dim3(SYN_BLOCK), 0, st, d_seg_start,
+                               d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,
+                               (const long long *)d_dst_off, (const long long *)d_fill_to, (float *)d_audio,
+                               (long long)audio_len, (const float *)ctx->d_sin_f32, ctx->quarter,
+                               (const wn_tone *)ctx->d_tones, ctx->n_tones, (const float *)ctx->d_per_f32);
+        else
+            hipLaunchKernelGGL(synth_period_kernel<int16_t>, dim3((unsigned)blocks), dim3(SYN_BLOCK), 0, st,
+                               d_seg_start, d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts,
+                               (int)part_len, (const long long *)d_dst_off, (const long long *)d_fill_to,
+                               (int16_t *)d_audio, (long long)audio_len, (const int16_t *)ctx->d_sin_i16, ctx->quarter,
+                               (const wn_tone *)ctx->d_tones, ctx->n_tones, (const int16_t *)ctx->d_per_i16);
+        return wn_launch_check("synth_period_kernel");
+    }
     if (fmt == WN_FMT_F32) {
         static size_t attr = 0;
         if (lds > attr) {
