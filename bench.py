@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=10000, help="streams per GPU")
     ap.add_argument("--cpu-streams", type=int, default=200, help="streams of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--sub-batches", type=int, default=0, help="split the streams of a step (0 = only if memory requires)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +98,7 @@ def main():
     nwin = stride // WIN
     free, _ = torch.cuda.mem_get_info()
     per_stream = stride * 4 + nwin * 10 + 4096
-    nb = 1
+    nb = max(1, args.sub_batches)
     while (S + nb - 1) // nb * per_stream > 0.6 * free:
         nb += 1
     sub = (S + nb - 1) // nb

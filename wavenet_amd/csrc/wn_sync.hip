@@ -13,15 +13,17 @@
 //     of the bins not computed is larger than the best ping bin;
 //   - otherwise undecided (2): only the full detection kernel can tell.
 //
-// One wave per window, lanes on consecutive float4s; each lane advances its twiddles by
-// a fixed rotation per step and the four samples of a float4 share one twiddle (their
-// offsets are applied once at the end), then a wavefront butterfly reduces the sums.
+// One wave per window; see the kernel for how the lanes walk it.
 #include <math.h>
 #include <string.h>
+
+#include <type_traits>
 
 #include "wn_common.h"
 
 #define SYNC_NB 8  // correlator bins per window
+
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 struct SyncBins {
     int n_ping;               // bins [0, n_ping) are the ping bins
@@ -39,12 +41,29 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
+// One wave per window.  Lanes take consecutive float4s, four per step (a wave has 4 KB of
+// contiguous HBM in flight); the 4 samples of a float4 share one twiddle per bin, their
+// offsets inside the float4 are applied once at the end, and the twiddle advances by a fixed
+// rotation (256 samples) from one float4 of the lane to its next.  A window's first twiddles
+// come from a table in LDS (bin x window alignment x lane).  Only the first and the last
+// step of a window can hold samples outside it; the steps between run without masks or
+// bounds checks.
 template <int NB>
-__global__ __launch_bounds__(256) void sync_kernel(const float *__restrict__ audio, long long audio_len,
+__global__ __launch_bounds__(256, 3) void sync_kernel(const float *__restrict__ audio, long long audio_len,
                                                    long long n_streams, long long stream_stride,
                                                    long long first_sample, long long n_windows, int N,
                                                    SyncBins sb, float *__restrict__ ping_energy,
                                                    float *__restrict__ win_energy, uint8_t *__restrict__ verdict) {
+    __shared__ float2 tw0[NB][4][64];   // twiddle of sample 4*lane - off, window alignment off
+    for (int i = threadIdx.x; i < NB * 4 * 64; i += 256) {
+        const int b = i >> 8, off = (i >> 6) & 3, l = i & 63;
+        int m = (sb.bin[b] * (4 * l - off)) % N;
+        m = m < 0 ? m + N : m;
+        float sn, cs;
+        sincospif((float)m * sb.inv_n2, &sn, &cs);
+        tw0[b][off][l] = make_float2(cs, sn);
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const long long total = n_streams * n_windows;
     const long long wstep = (long long)gridDim.x * 4;
@@ -53,57 +72,60 @@ __global__ __launch_bounds__(256) void sync_kernel(const float *__restrict__ aud
         const long long g0 = s * stream_stride + first_sample + (w - s * n_windows) * (long long)N;
         const long long a0 = g0 & ~3ll;
         const int off = (int)(g0 - a0);
-        // twiddle of this lane's first float4: sample index n0 = 4*lane - off (may be < 0)
-        float2 tw[NB];
+        const float *base = audio + a0 + 4 * lane;
+        floatx2 tw[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            int m = (int)(((long long)sb.bin[b] * (4 * lane - off)) % N);
-            m = m < 0 ? m + N : m;
-            float sn, cs;
-            sincospif((float)m * sb.inv_n2, &sn, &cs);
-            tw[b] = make_float2(cs, sn);
+            const float2 t = tw0[b][off][lane];
+            tw[b] = (floatx2){t.x, t.y};
         }
-        float are[NB][4], aim[NB][4];
+        floatx2 acc[NB][4];   // (re, im) sums per bin and position in the float4: packed FMAs
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) are[b][q] = aim[b][q] = 0.f;
+            for (int q = 0; q < 4; ++q) acc[b][q] = (floatx2){0.f, 0.f};
         float sx = 0.f, sxx = 0.f;
         const int nv = (N + off + 3) / 4;  // float4s covering the window
-        // four float4 loads in flight per lane before any arithmetic: the kernel is a pure
-        // stream and needs the bytes in flight to cover HBM latency
-        for (int j0 = lane; j0 < nv; j0 += 256) {
+        auto step = [&](auto EDGE, int it) {
+            constexpr bool edge = decltype(EDGE)::value;
             float4 vv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = 4 * (j0 + 64 * u);
-                vv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (j0 + 64 * u < nv && a0 + e + 4 <= audio_len) vv[u] = *(const float4 *)(audio + a0 + e);
+                const int j = lane + 64 * u + 256 * it;
+                if constexpr (edge) {
+                    vv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < nv && a0 + 4 * j + 4 <= audio_len) vv[u] = *(const float4 *)(base + 256 * u + 1024 * it);
+                } else {
+                    vv[u] = *(const float4 *)(base + 256 * u + 1024 * it);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int n0 = 4 * (j0 + 64 * u) - off;
                 float x[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+                if constexpr (edge) {
+                    const int n0 = 4 * (lane + 64 * u + 256 * it) - off;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = (n0 + q >= 0 && n0 + q < N) ? x[q] : 0.f;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + q;
-                    x[q] = (n >= 0 && n < N) ? x[q] : 0.f;
                     sx += x[q];
                     sxx = fmaf(x[q], x[q], sxx);
                 }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        are[b][q] = fmaf(x[q], tw[b].x, are[b][q]);
-                        aim[b][q] = fmaf(x[q], tw[b].y, aim[b][q]);
-                    }
-                    const float c = tw[b].x * sb.step[b].x - tw[b].y * sb.step[b].y;
-                    const float sn = tw[b].x * sb.step[b].y + tw[b].y * sb.step[b].x;
-                    tw[b] = make_float2(c, sn);
+                    for (int q = 0; q < 4; ++q)
+                        acc[b][q] = __builtin_elementwise_fma((floatx2){x[q], x[q]}, tw[b], acc[b][q]);
+                    const floatx2 t = tw[b];
+                    tw[b] = (floatx2){t.x * sb.step[b].x - t.y * sb.step[b].y, t.x * sb.step[b].y + t.y * sb.step[b].x};
                 }
             }
-        }
+        };
+        const int last = (nv - 1) / 256;
+        step(std::true_type{}, 0);
+        for (int it = 1; it < last; ++it) step(std::false_type{}, it);
+        if (last > 0) step(std::true_type{}, last);
         // apply the in-float4 offsets, reduce over the wave
         float mag2[NB];
 #pragma unroll
@@ -112,8 +134,8 @@ __global__ __launch_bounds__(256) void sync_kernel(const float *__restrict__ aud
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // (are + i*aim) * (rot.x + i*rot.y)
-                re += are[b][q] * sb.rot[b][q].x - aim[b][q] * sb.rot[b][q].y;
-                im += are[b][q] * sb.rot[b][q].y + aim[b][q] * sb.rot[b][q].x;
+                re += acc[b][q].x * sb.rot[b][q].x - acc[b][q].y * sb.rot[b][q].y;
+                im += acc[b][q].x * sb.rot[b][q].y + acc[b][q].y * sb.rot[b][q].x;
             }
             re = wave_sum_f(re);
             im = wave_sum_f(im);
