@@ -91,3 +91,32 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         M.Modem()
+
+
+def test_entry_points_reject_bad_arguments_before_touching_a_device():
+    """Argument checks come first: with a null context or pointers every entry point returns
+    WN_ERR_ARG and says which argument, without launching anything."""
+    import ctypes as C
+    null = C.c_void_p(None)
+    lib = L.lib
+    calls = [
+        lambda: lib.wn_crc32_batch(null, null, null, 128, 1, null, null),
+        lambda: lib.wn_frame_build_batch(null, null, null, 112, 1, null, 128, null, null),
+        lambda: lib.wn_frame_parse_validate_batch(null, null, null, 128, 1, null, null),
+        lambda: lib.wn_synth_layout(null, null, null, 128, 1, 0, 300, null, null, null, null, null),
+        lambda: lib.wn_synth_batch(null, null, null, null, 300, 1, null, null, 1000, null, 1000, 0, null),
+        lambda: lib.wn_channel_awgn(null, null, 10, 0.1, 1, null),
+        lambda: lib.wn_detect_windows(null, null, 7056, 1, 7056, 0, 1, null, null, null, null),
+        lambda: lib.wn_sync_scan(null, null, 7056, 1, 7056, 0, 1, null, null, null, null),
+        lambda: lib.wn_slice_frames(null, null, 1, 1, 10, 1, 128, null, null, null, null, null, null, null),
+        lambda: lib.wn_detect_set_tie_band(null, 0.1),
+        lambda: lib.wn_selftest_mfma(null, null),
+    ]
+    for i, call in enumerate(calls):
+        assert call() == L.WN_ERR_ARG, i
+        assert lib.wn_last_error().startswith(b"bad argument"), (i, lib.wn_last_error())
+    assert lib.wn_ctx_destroy(null) == 0
+    assert lib.wn_strerror(L.WN_ERR_ARG) and lib.wn_strerror(0)
+    bad = L.WnScheme()          # all zeros: not a scheme
+    ctx = C.c_void_p()
+    assert lib.wn_scheme_init(C.byref(bad), C.byref(ctx)) == L.WN_ERR_ARG and not ctx.value

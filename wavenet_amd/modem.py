@@ -96,8 +96,9 @@ class Modem:
 
     def __del__(self):
         ctx = getattr(self, "_ctx", None)
-        if ctx:
-            L.lib.wn_ctx_destroy(ctx)
+        lib = getattr(L, "lib", None)     # module globals may already be gone at interpreter exit
+        if ctx and lib is not None:
+            lib.wn_ctx_destroy(ctx)
             self._ctx = None
 
     # ------------------------------------------------------------------ K4
