@@ -489,6 +489,44 @@ def test_roundtrip_many_streams_max_payload(mb):
         assert int(out["end"][i, 0]) == used
 
 
+def test_empty_and_smallest_inputs(mb, ma):
+    """Nothing to do is not an error: zero frames, zero streams, zero windows; and the
+    smallest real cases: an empty payload, one window, a capture shorter than any frame."""
+    z8 = torch.zeros((0, 128), dtype=torch.uint8, device="cuda")
+    z32 = torch.zeros((0,), dtype=torch.int32, device="cuda")
+    assert mb.crc32(z8, z32).numel() == 0
+    assert mb.parse_frames(z8, z32).numel() == 0
+    frames, lens = mb.build_frames(torch.zeros((0, 16), dtype=torch.uint8, device="cuda"),
+                                   torch.zeros((0, 112), dtype=torch.uint8, device="cuda"), 128)
+    assert frames.shape[0] == 0 and lens.numel() == 0
+    audio = torch.zeros(M.pad4(7055), dtype=torch.float32, device="cuda")
+    cls, mag, kbin = mb.detect(audio, 0, 0, 0)
+    assert cls.numel() == 0
+    cls, mag, kbin = mb.detect(audio, 1, audio.numel(), 0)
+    assert cls.shape == (1, 0)
+    by, ln, st, en, rs, nc = mb.slice(torch.zeros((1, 0), dtype=torch.int16, device="cuda"), 10, 1, 128)
+    assert int(nc[0]) == 0
+    # one silent window: bin 0, its class, magnitude 0; the listener times out empty-handed
+    cls, mag, kbin = mb.detect(audio, 1, audio.numel(), 1)
+    assert int(kbin[0, 0]) == 0 and float(mag[0, 0]) == 0.0
+    by, ln, st, en, rs, nc = mb.slice(cls, 10, 1, 128)
+    assert int(nc[0]) == 1 and int(ln[0, 0]) == 0 and int(en[0, 0]) == 1 and int(rs[0, 0]) == L.END_TIMEOUT
+    # empty payload: the 19-byte ping frame, through the whole path
+    f = mo.build_frame(1, MAC_O, MAC_D, 1, b"")
+    buf, lens = rows_from([f], 32)
+    stride = M.pad4(len(mo.emit_frame(f, SB)) + 7055)
+    a, n = mb.encode_streams(dev(buf), dev(lens), stride)
+    out = mb.decode_streams(a, 1, stride, stride // 7055, 30.0, frame_cap=32)
+    assert bytes(out["bytes"][0, 0, :int(out["lens"][0, 0])].cpu().numpy()) == f
+    rec = M.Modem.records_to_numpy(out["rec"])[0]
+    assert rec["status"] == L.ST_OK and rec["crc_ok"] == 1 and rec["length"] == 0
+    # the prototype scheme: a single one-byte message
+    buf, lens = rows_from([b"\x07"], 16)
+    a, n = ma.encode_streams(dev(buf), dev(lens), M.pad4(2 * 2205))
+    cls, _, _ = ma.detect(a, 1, a.shape[1], 1)
+    assert int(cls[0, 0]) & 0x1FF == 7
+
+
 def test_awgn_statistics(mb):
     a = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
     mb.awgn(a, 0.1, 1234)

@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, int iters, unsigned 
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = make_float2(j, threadIdx.x);
     float l = 0;
+    unsigned sc[4] = {1, 2, 3, 4};
+    float gl[4] = {0, 0, 0, 0};
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -80,6 +82,15 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, int iters, unsigned 
                 M_AGPR(i);
 #pragma unroll
                 for (int j = 0; j < K; ++j) ACCRD(j, i);
+            } else if constexpr (MODE == 11) {  // MFMA + K scalar adds
+                M_AGPR(i);
+#pragma unroll
+                for (int j = 0; j < K; ++j) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sc[j & 3]) : "s"(it) : "scc");
+            } else if constexpr (MODE == 12) {  // MFMA + K global loads (waited for at the end of the iteration)
+                M_AGPR(i);
+#pragma unroll
+                for (int j = 0; j < K; ++j) asm volatile("global_load_dword %0, %1, off" : "=v"(gl[j & 3]) : "v"(out + ((threadIdx.x + 64 * j) & 1023)) : "memory");
+                if (i == NACC - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else if constexpr (MODE == 10) {  // MFMA + K v_lshl_add_u32
                 M_AGPR(i);
 #pragma unroll
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, int iters, unsigned 
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += v[j] + u[j];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s += p[j].x + p[j].y;
+    for (int j = 0; j < 4; ++j) s += p[j].x + p[j].y + sc[j] + gl[j];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
@@ -104,7 +115,7 @@ int main() {
     const int iters = 3000;
     const char *names[] = {"agpr acc + v_add_f32", "vgpr acc + v_add_f32", "vgpr acc, B in agpr + v_add_f32", "v_min_u32",
                            "v_cmp/s_nop 1/v_cndmask", "v_med3_u32", "3 mfma then 3K v_add_f32", "v_pk_add_f32",
-                           "ds_read_b32", "v_accvgpr_read", "v_lshl_add_u32"};
+                           "ds_read_b32", "v_accvgpr_read", "v_lshl_add_u32", "s_add_u32", "global_load_dword"};
 #define RUN(MODE, K)                                                                  \
     {                                                                                 \
         probe<MODE, K><<<256, 256>>>(out, iters, cyc);                                \
@@ -113,10 +124,7 @@ int main() {
         printf("%-34s K=%d: %.1f clocks/mfma\n", names[MODE], K, (double)h / ((double)iters * 36)); \
     }
 #define RUNS(MODE) RUN(MODE, 0) RUN(MODE, 2) RUN(MODE, 4) RUN(MODE, 5) RUN(MODE, 6) RUN(MODE, 7) RUN(MODE, 8)
-    RUNS(0) RUNS(1) RUNS(2) RUNS(3)
-    RUN(4, 1) RUN(4, 2) RUN(4, 3) RUN(4, 4)
-    RUNS(5) RUNS(6) RUNS(7)
-    RUN(8, 1) RUN(8, 2) RUN(8, 4)
-    RUNS(9) RUNS(10)
+    RUN(0, 0) RUN(0, 2)
+    RUN(11, 2) RUN(11, 4) RUN(11, 8) RUN(12, 1) RUN(12, 2) RUN(12, 4)
     return 0;
 }
