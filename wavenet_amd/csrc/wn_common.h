@@ -61,6 +61,16 @@ void wn_set_error(const char *fmt, ...);
         }                                            \
     } while (0)
 
+// Entry points that launch work: the current device must be the one the context was built
+// on (its tables live there).  Returns WN_OK or WN_ERR_ARG with the two device numbers.
+int wn_device_check(const wn_ctx *ctx);
+#define WN_REQUIRE_DEVICE(ctx)            \
+    do {                                  \
+        int rc_dev_ = wn_device_check(ctx); \
+        if (rc_dev_ != WN_OK) return rc_dev_; \
+    } while (0)
+#define WN_MAX_DEVICES 64   // per-device bookkeeping of function attributes
+
 static inline int wn_launch_check(const char *kernel) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

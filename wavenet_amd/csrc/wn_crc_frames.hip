@@ -194,6 +194,7 @@ template <int MODE>
 static int launch_rows(wn_ctx *ctx, const uint8_t *rows, const int32_t *lens, int32_t stride, int64_t n,
                        uint32_t *out32, wn_frame_rec *out_rec, hipStream_t st) {
     if (n == 0) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
     const bool tiled = (stride % 16 == 0) && stride >= 16 && stride <= 512 && (((uintptr_t)rows) % 16 == 0);
     if (tiled) {
         const size_t lds = 4096 + (size_t)CRC_WAVES * 64 * (stride + 4);
@@ -201,11 +202,11 @@ static int launch_rows(wn_ctx *ctx, const uint8_t *rows, const int32_t *lens, in
         long long blocks = (tiles + CRC_WAVES - 1) / CRC_WAVES;
         const long long cap = (long long)ctx->num_cus * 8;
         if (blocks > cap) blocks = cap;
-        static size_t attr_lds[2] = {48 * 1024, 48 * 1024};
-        if (lds > attr_lds[MODE]) {
+        static size_t attr_lds[WN_MAX_DEVICES];   // largest dynamic LDS size allowed so far, per device
+        if (lds > 48 * 1024 && lds > attr_lds[ctx->device]) {
             WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_rows_kernel<MODE>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_lds[MODE] = lds;
+            attr_lds[ctx->device] = lds;
         }
         hipLaunchKernelGGL(crc_rows_kernel<MODE>, dim3((unsigned)blocks), dim3(CRC_BLOCK), lds, st, rows, lens,
                            (int)stride, (long long)n, ctx->d_crc_tab, out32, out_rec);
@@ -241,6 +242,7 @@ extern "C" int wn_frame_build_batch(wn_ctx *ctx, const uint8_t *d_fields, const 
     WN_REQUIRE(n == 0 || (d_fields && d_frames && d_frame_lens && (d_payloads || payload_stride == 0)),
                "null device pointer");
     if (n == 0) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
     long long blocks = (n + CRC_BLOCK - 1) / CRC_BLOCK;
     const long long cap = (long long)ctx->num_cus * 8;
     if (blocks > cap) blocks = cap;

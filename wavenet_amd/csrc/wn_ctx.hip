@@ -187,6 +187,16 @@ static int upload(T **dptr, const T *host, size_t count) {
     return WN_OK;
 }
 
+int wn_device_check(const wn_ctx *ctx) {
+    int dev = -1;
+    WN_HIP_TRY(hipGetDevice(&dev));
+    if (dev != ctx->device || dev < 0 || dev >= WN_MAX_DEVICES) {
+        wn_set_error("bad argument: the context belongs to device %d, the current device is %d", ctx->device, dev);
+        return WN_ERR_ARG;
+    }
+    return WN_OK;
+}
+
 extern "C" int wn_ctx_destroy(wn_ctx *ctx) {
     if (!ctx) return WN_OK;
     hipFree(ctx->d_sin_f32);
@@ -248,6 +258,11 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
     } while (0)
 
     INIT_HIP(hipGetDevice(&ctx->device));
+    if (ctx->device >= WN_MAX_DEVICES) {
+        wn_set_error("device index %d not supported", ctx->device);
+        wn_ctx_destroy(ctx);
+        return WN_ERR_UNSUPPORTED;
+    }
     hipDeviceProp_t prop;
     INIT_HIP(hipGetDeviceProperties(&prop, ctx->device));
     ctx->num_cus = prop.multiProcessorCount;

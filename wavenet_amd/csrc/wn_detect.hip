@@ -662,7 +662,8 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
                          int64_t stream_stride, int64_t first_sample, int64_t n_windows, uint16_t *d_cls,
                          float *d_mag, int32_t *d_bin, hipStream_t st) {
     typedef Plan<N1, N2> P;
-    static bool attr = false;
+    static bool attr_done[WN_MAX_DEVICES];
+    bool &attr = attr_done[ctx->device];
     if (!attr) {
         WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS));
@@ -708,6 +709,7 @@ extern "C" int wn_detect_windows(wn_ctx *ctx, const float *d_audio, int64_t audi
                                  float *d_peak_mag, int32_t *d_peak_bin, void *stream) {
     WN_REQUIRE(ctx && n_streams >= 0 && n_windows >= 0 && first_sample >= 0 && stream_stride >= 0, "ctx / sizes");
     if (n_streams == 0 || n_windows == 0) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
     WN_REQUIRE(d_audio && d_cls && d_peak_mag && d_peak_bin, "null device pointer");
     WN_REQUIRE(((uintptr_t)d_audio % 16) == 0 && audio_len % 4 == 0, "d_audio 16-byte aligned, audio_len % 4 == 0");
     const int64_t span = first_sample + n_windows * (int64_t)ctx->n;

@@ -171,6 +171,7 @@ extern "C" int wn_slice_frames(wn_ctx *ctx, const uint16_t *d_cls, int64_t n_str
                                   (d_cls || n_windows == 0)),
                "null device pointer");
     if (n_streams == 0) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
     if (ctx->s.sep_freq != 0) {
         WN_REQUIRE(n_streams < (1ll << 31), "n_streams < 2^31");
         hipLaunchKernelGGL(slice_wave_kernel, dim3((unsigned)n_streams), dim3(64), 0, (hipStream_t)stream, d_cls,

@@ -196,6 +196,7 @@ extern "C" int wn_sync_scan(wn_ctx *ctx, const float *d_audio, int64_t audio_len
         return WN_ERR_UNSUPPORTED;
     }
     if (n_streams == 0 || n_windows == 0) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
     WN_REQUIRE(d_audio && d_ping_energy && d_win_energy && d_verdict, "null device pointer");
     WN_REQUIRE(((uintptr_t)d_audio % 16) == 0 && audio_len % 4 == 0, "d_audio 16-byte aligned, audio_len % 4 == 0");
     const int64_t span = first_sample + n_windows * (int64_t)ctx->n;

@@ -392,6 +392,7 @@ extern "C" int wn_synth_layout(wn_ctx *ctx, const uint8_t *d_frames, const int32
     WN_REQUIRE(n == 0 || (d_frames && d_lens && d_seg_start && d_seg_freq && d_n_segs && d_n_samples),
                "null device pointer");
     if (n == 0) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
     const unsigned blocks = (unsigned)((n + 127) / 128);
     hipLaunchKernelGGL(synth_layout_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ctx->s, d_frames,
                        d_lens, (int)stride, (long long)n, (int)variant, (int)seg_cap, d_seg_start, d_seg_freq,
@@ -409,6 +410,7 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     WN_REQUIRE(slot_len > 0 && slot_len < (1ll << 31) && audio_len > 0, "0 < slot_len < 2^31 / audio_len > 0");
     WN_REQUIRE(n == 0 || (d_seg_start && d_seg_freq && d_n_segs && d_dst_off && d_audio), "null device pointer");
     if (n == 0) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
     const size_t esz = fmt == WN_FMT_F32 ? 4 : 2;
     const bool tabulated = ctx->n_tones > 0 && ctx->n_tones <= SYN_MAX_TONES;
     const size_t tab_entries = ((size_t)ctx->quarter + 1 + 31) & ~(size_t)31;
@@ -453,7 +455,8 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
         return wn_launch_check("synth_period_kernel");
     }
     if (fmt == WN_FMT_F32) {
-        static size_t attr = 0;
+        static size_t attr_lds[WN_MAX_DEVICES];
+        size_t &attr = attr_lds[ctx->device];
         if (lds > attr) {
             WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<float>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -464,7 +467,8 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
                            (const long long *)d_dst_off, (const long long *)d_fill_to, (float *)d_audio,
                            (long long)audio_len, (const float *)ctx->d_sin_f32, ctx->quarter);
     } else {
-        static size_t attr = 0;
+        static size_t attr_lds[WN_MAX_DEVICES];
+        size_t &attr = attr_lds[ctx->device];
         if (lds > attr) {
             WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<int16_t>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -482,6 +486,7 @@ extern "C" int wn_channel_awgn(wn_ctx *ctx, float *d_audio, int64_t n, float sig
     WN_REQUIRE(ctx && n >= 0 && sigma >= 0.0f, "ctx / n >= 0 / sigma >= 0");
     WN_REQUIRE(n == 0 || d_audio, "null device pointer");
     if (n == 0 || sigma == 0.0f) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
     const long long pairs = (n + 1) / 2;
     long long blocks = (pairs + 255) / 256;
     const long long cap = (long long)ctx->num_cus * 16;
