@@ -90,6 +90,11 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+        # communicator set-up is not part of a step: run the collectives the steps use once,
+        # on empty-sized data, before anything is timed (also when --warmup is 0)
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=device), op=dist.ReduceOp.MAX)
+        SH.gather_records(torch.zeros((1, SH.RECORD_BYTES), dtype=torch.uint8, device=device), world, dst=0)
+        dist.barrier()
 
     m = M.Modem(M.esquema_b())
     n1, n2 = M.host_dft_plan(m.esquema)
