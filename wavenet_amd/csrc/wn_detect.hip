@@ -54,6 +54,7 @@
 #include <utility>
 
 #include "wn_common.h"
+#include "wn_dma.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -152,39 +153,6 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7"
 __device__ __forceinline__ void acc_const(float &dst, float v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); }
 // ties a register's later readers to this point of the (ordered) asm sequence
 __device__ __forceinline__ void after_drain(floatx4 &v) { asm volatile("" : "+v"(v)); }
-
-// CNT loads of 16 (X4) or 4 bytes per lane from p + j*STRIDE bytes straight into LDS at
-// lds + j*STRIDE + lane*(16 or 4): the immediate offset applies to both addresses.  M0 holds
-// the LDS base for the duration and is restored.
-template <int CNT, int STRIDE, bool X4>
-__device__ __forceinline__ void dma_group(const float *p, unsigned lds) {
-    static_assert(CNT >= 1 && CNT <= 4, "group size");
-    unsigned keep_m0;
-#define WN_DMA_ASM(OP)                                                                                       \
-    if constexpr (CNT == 1)                                                                                  \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep_m0) : "v"(p), "s"(lds) : "memory");                                        \
-    else if constexpr (CNT == 2)                                                                             \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
-                     " %1, off offset:%3\n\ts_mov_b32 m0, %0"                                                \
-                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE) : "memory");                           \
-    else if constexpr (CNT == 3)                                                                             \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
-                     " %1, off offset:%3\n\t" OP " %1, off offset:%4\n\ts_mov_b32 m0, %0"                    \
-                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE), "n"(2 * STRIDE) : "memory");          \
-    else                                                                                                     \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
-                     " %1, off offset:%3\n\t" OP " %1, off offset:%4\n\t" OP                                 \
-                     " %1, off offset:%5\n\ts_mov_b32 m0, %0"                                                \
-                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE)      \
-                     : "memory");
-    if constexpr (X4) {
-        WN_DMA_ASM("global_load_lds_dwordx4")
-    } else {
-        WN_DMA_ASM("global_load_lds_dword")
-    }
-#undef WN_DMA_ASM
-}
 
 template <int CTRL, int ROWS>
 __device__ __forceinline__ unsigned dpp_u(unsigned v) {

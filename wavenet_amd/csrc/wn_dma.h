@@ -1,0 +1,37 @@
+// Window staging by LDS-DMA (global_load_lds): shared by the detection and sync kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// CNT loads of 16 (X4) or 4 bytes per lane from p + j*STRIDE bytes straight into LDS at
+// lds + j*STRIDE + lane*(16 or 4): the immediate offset applies to both addresses.  M0 holds
+// the LDS base for the duration and is restored.
+template <int CNT, int STRIDE, bool X4>
+__device__ __forceinline__ void dma_group(const float *p, unsigned lds) {
+    static_assert(CNT >= 1 && CNT <= 4, "group size");
+    unsigned keep_m0;
+#define WN_DMA_ASM(OP)                                                                                       \
+    if constexpr (CNT == 1)                                                                                  \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_m0) : "v"(p), "s"(lds) : "memory");                                        \
+    else if constexpr (CNT == 2)                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
+                     " %1, off offset:%3\n\ts_mov_b32 m0, %0"                                                \
+                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE) : "memory");                           \
+    else if constexpr (CNT == 3)                                                                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
+                     " %1, off offset:%3\n\t" OP " %1, off offset:%4\n\ts_mov_b32 m0, %0"                    \
+                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE), "n"(2 * STRIDE) : "memory");          \
+    else                                                                                                     \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t" OP " %1, off\n\t" OP              \
+                     " %1, off offset:%3\n\t" OP " %1, off offset:%4\n\t" OP                                 \
+                     " %1, off offset:%5\n\ts_mov_b32 m0, %0"                                                \
+                     : "=&s"(keep_m0) : "v"(p), "s"(lds), "n"(STRIDE), "n"(2 * STRIDE), "n"(3 * STRIDE)      \
+                     : "memory");
+    if constexpr (X4) {
+        WN_DMA_ASM("global_load_lds_dwordx4")
+    } else {
+        WN_DMA_ASM("global_load_lds_dword")
+    }
+#undef WN_DMA_ASM
+}
+

@@ -4,7 +4,7 @@
 // (c1_shared.py:330-335), without computing the spectrum.
 //
 // Per window the kernel reads the samples once (HBM-read-bound, 4 bytes per sample) and
-// accumulates sum(x), sum(x^2) and a handful of DFT bins by direct correlation: the ping
+// computes sum(x), sum(x^2) and a handful of DFT bins by direct correlation: the ping
 // bins, a few rival bins (nearest bins of the separator, EOF and byte-0 tones) and the
 // one bin of [1, N/2] that np.argmax never looks at.  Parseval then bounds every bin not
 // computed:   sum_{k=1..(N-1)/2} |X_k|^2 = (N*sum(x^2) - X_0^2) / 2   (N odd), so
@@ -13,156 +13,253 @@
 //     of the bins not computed is larger than the best ping bin;
 //   - otherwise undecided (2): only the full detection kernel can tell.
 //
-// One wave per window; see the kernel for how the lanes walk it.
+// The correlations run on the matrix cores; see the kernel.
 #include <math.h>
 #include <string.h>
 
 #include <type_traits>
 
 #include "wn_common.h"
+#include "wn_dma.h"
 
-#define SYNC_NB 8  // correlator bins per window
+#define SYNC_NB 8  // correlator bins per window (at most 7 are used: rows 0..13 of the MFMA tile)
 
-typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 struct SyncBins {
     int n_ping;               // bins [0, n_ping) are the ping bins
     int n_used;               // bins [n_ping, n_used) are rivals; slot n_used = excluded bin
+    int n_bins;               // n_used + 1
     int bin[SYNC_NB];
-    float2 step[SYNC_NB];     // rotation by 256 samples
-    float2 rot[SYNC_NB][4];   // rotation by q = 0..3 samples
     float inv_n2;             // 2 / N
     int others;               // bins of [1, N/2) that are not computed
 };
 
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+template <int N>
+struct SyncPlan {
+    static constexpr int CH = 256;                          // samples per chunk = one 1-KiB DMA piece
+    static constexpr int PITCH = CH + 4;                    // floats between chunks in LDS (bank spread)
+    static constexpr int NV4MAX = (N + 3 + 3) / 4;          // float4s of a window at the worst alignment
+    static constexpr int NCH = (4 * NV4MAX + CH - 1) / CH;  // chunks that can hold data
+    static constexpr int G = (NCH + 15) / 16;               // column groups of 16 chunks
+    static constexpr int BUF = G * 16 * PITCH;              // floats of LDS per wave
+    static constexpr int R1 = NCH > 16 ? NCH - 16 : 0;      // DMA pieces of the second group
+    static_assert(G == 1 || G == 2, "window length");
+    static constexpr size_t LDS = (size_t)4 * BUF * 4;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float row_add(float v) {   // v + the value of the lane the DPP control pairs it with
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {   // v of a given lane, in every lane
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// sum over the 16 lanes of a DPP row, left in every lane of the row
+__device__ __forceinline__ float row_sum(float v) {
+    v = row_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = row_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = row_add<0x141>(v);   // row_half_mirror
+    v = row_add<0x140>(v);   // row_mirror
     return v;
 }
 
-// One wave per window.  Lanes take consecutive float4s, four per step (a wave has 4 KB of
-// contiguous HBM in flight); the 4 samples of a float4 share one twiddle per bin, their
-// offsets inside the float4 are applied once at the end, and the twiddle advances by a fixed
-// rotation (256 samples) from one float4 of the lane to its next.  A window's first twiddles
-// come from a table in LDS (bin x window alignment x lane).  Only the first and the last
-// step of a window can hold samples outside it; the steps between run without masks or
-// bounds checks.
-template <int NB>
-__global__ __launch_bounds__(256, 3) void sync_kernel(const float *__restrict__ audio, long long audio_len,
-                                                   long long n_streams, long long stream_stride,
-                                                   long long first_sample, long long n_windows, int N,
-                                                   SyncBins sb, float *__restrict__ ping_energy,
-                                                   float *__restrict__ win_energy, uint8_t *__restrict__ verdict) {
-    __shared__ float2 tw0[NB][4][64];   // twiddle of sample 4*lane - off, window alignment off
-    for (int i = threadIdx.x; i < NB * 4 * 64; i += 256) {
-        const int b = i >> 8, off = (i >> 6) & 3, l = i & 63;
-        int m = (sb.bin[b] * (4 * l - off)) % N;
-        m = m < 0 ? m + N : m;
-        float sn, cs;
-        sincospif((float)m * sb.inv_n2, &sn, &cs);
-        tw0[b][off][l] = make_float2(cs, sn);
-    }
-    __syncthreads();
+// One wave per window, on the matrix cores.  The window is cut into chunks of 256 samples;
+// a correlation over the window is the sum over chunks c of (chunk correlation) x
+// exp(-i*theta*256*c), and the chunk correlations of 16 chunks at once are one small matrix
+// product: A (16 x 256) holds cos / -sin of up to 7 bins and a row of ones (sum of x), the
+// same for every chunk, so each lane keeps its 64 entries in registers for the whole launch;
+// B (256 x 16) is 16 chunks of the window, read from LDS.  v_mfma_f32_16x16x4_f32, 64 per 16
+// chunks.  The window is staged by DMA, one 1-KiB piece per chunk at a pitch of 260 floats
+// (conflict-free 16-byte reads); the buffer has two halves (chunks 0-15, 16-31) and the
+// next window's half is fetched as soon as this window's half has been read.  Window
+// starts are not 16-byte aligned: position p of the buffer is sample p - off, which only
+// turns the phase of every bin; the up to 3 positions before the window and the few after
+// it are zeroed.  sum(x^2) is accumulated by the vector ALU from the same reads.
+template <int N>
+__global__ __launch_bounds__(256, 1) void sync_kernel(const float *__restrict__ audio, long long n_streams,
+                                                      long long stream_stride, long long first_sample,
+                                                      long long n_windows, SyncBins sb,
+                                                      float *__restrict__ ping_energy, float *__restrict__ win_energy,
+                                                      uint8_t *__restrict__ verdict) {
+    typedef SyncPlan<N> P;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    float *buf = (float *)smem + wave * P::BUF;
+    for (int i = lane; i < P::BUF; i += 64) buf[i] = 0.f;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)buf;
+
+    // A operand: row li, k index (4j + e) <-> position 16j + 4lg + e of a chunk
+    const int row_bin = li >> 1;
+    const bool row_live = row_bin < sb.n_bins, row_ones = li == 14;
+    float a_tab[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const int p = 16 * (k >> 2) + 4 * lg + (k & 3);
+        float sn, cs;
+        sincospif((float)((sb.bin[row_bin & 7] * p) % N) * sb.inv_n2, &sn, &cs);
+        a_tab[k] = row_ones ? 1.f : (row_live ? ((li & 1) ? -sn : cs) : 0.f);
+    }
+    // chunk c = 16g + li of this lane's column: exp(-i*theta*256*c) for the lane's two bins
+    // (rows 4lg, 4lg+1 and 4lg+2, 4lg+3 of the result tile)
+    float wc[P::G][2], ws[P::G][2];
+#pragma unroll
+    for (int g = 0; g < P::G; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = 2 * lg + h;
+            float sn, cs;
+            sincospif((float)(((long long)sb.bin[b & 7] * 256 * (16 * g + li)) % N) * sb.inv_n2, &sn, &cs);
+            wc[g][h] = b < sb.n_bins ? cs : 0.f;
+            ws[g][h] = b < sb.n_bins ? -sn : 0.f;
+        }
+
     const long long total = n_streams * n_windows;
     const long long wstep = (long long)gridDim.x * 4;
-    for (long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += wstep) {
-        const long long s = w / n_windows;
-        const long long g0 = s * stream_stride + first_sample + (w - s * n_windows) * (long long)N;
-        const long long a0 = g0 & ~3ll;
-        const int off = (int)(g0 - a0);
-        const float *base = audio + a0 + 4 * lane;
-        floatx2 tw[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float2 t = tw0[b][off][lane];
-            tw[b] = (floatx2){t.x, t.y};
+    long long w = (long long)blockIdx.x * 4 + wave;
+    // (stream, window) of the window to fetch next, advanced without divisions
+    const long long adv_s = wstep / n_windows, adv_w = wstep - adv_s * n_windows;
+    long long f_s = w / n_windows, f_w = w - f_s * n_windows;
+    const float *f_base = nullptr;   // 16-byte aligned start of the window being fetched
+    int f_off = 0, f_nv4 = 0;
+    auto fetch_begin = [&]() {
+        const long long g0 = f_s * stream_stride + first_sample + f_w * (long long)N;
+        f_off = (int)(g0 & 3);
+        f_base = audio + (g0 - f_off) + 4 * lane;
+        f_nv4 = (N + f_off + 3) / 4;
+        f_s += adv_s;
+        f_w += adv_w;
+        if (f_w >= n_windows) {
+            f_w -= n_windows;
+            f_s += 1;
         }
-        floatx2 acc[NB][4];   // (re, im) sums per bin and position in the float4: packed FMAs
+    };
+    auto fetch_half = [&](auto H) {   // chunks [16h, 16h+16) of the window: one piece per chunk
+        constexpr int h = decltype(H)::value;
+        constexpr int c0 = 16 * h, c1 = (P::NCH < c0 + 16 ? P::NCH : c0 + 16);
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[b][q] = (floatx2){0.f, 0.f};
-        float sx = 0.f, sxx = 0.f;
-        const int nv = (N + off + 3) / 4;  // float4s covering the window
-        auto step = [&](auto EDGE, int it) {
-            constexpr bool edge = decltype(EDGE)::value;
-            float4 vv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = lane + 64 * u + 256 * it;
-                if constexpr (edge) {
-                    vv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (j < nv && a0 + 4 * j + 4 <= audio_len) vv[u] = *(const float4 *)(base + 256 * u + 1024 * it);
-                } else {
-                    vv[u] = *(const float4 *)(base + 256 * u + 1024 * it);
-                }
+        for (int c = c0; c < c1; ++c) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + 4u * P::PITCH * c);
+            if (64 * (c + 1) <= P::NV4MAX - 1) {            // whole piece inside every window
+                dma_group<1, 1024, true>(f_base + 256 * c, dst);
+            } else {                                         // the last piece: only the float4s of the window
+                if (64 * c + lane < f_nv4) dma_group<1, 1024, true>(f_base + 256 * c, dst);
             }
+        }
+    };
+    auto fix_head = [&](int off) {   // positions before the window
+        if (lane < off) buf[lane] = 0.f;
+    };
+    auto fix_tail = [&](int off) {   // positions after it, up to the end of the last float4 any alignment writes
+        const int p = off + N + lane;
+        if (p < 4 * P::NV4MAX) buf[P::PITCH * (p >> 8) + (p & 255)] = 0.f;
+    };
+
+    bool pend = false;
+    long long pend_w = 0;
+    float pend_pe = 0.f, pend_we = 0.f;
+    unsigned pend_v = 0;
+    auto flush = [&]() {
+        if (pend && lane == 0) {
+            ping_energy[pend_w] = pend_pe;
+            win_energy[pend_w] = pend_we;
+            verdict[pend_w] = (uint8_t)pend_v;
+        }
+    };
+
+    int off = 0;
+    if (w < total) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill above is in LDS
+        fetch_begin();
+        off = f_off;
+        fetch_half(std::integral_constant<int, 0>{});
+        if constexpr (P::G == 2) fetch_half(std::integral_constant<int, 1>{});
+    }
+    while (w < total) {
+        const long long wn = w + wstep;
+        const bool more = wn < total;
+        float xr[2] = {0.f, 0.f}, xi[2] = {0.f, 0.f}, sxx = 0.f;
+        int next_off = 0;
+        auto group = [&](auto GG) {
+            constexpr int g = decltype(GG)::value;
+            const float *col = buf + P::PITCH * (16 * g + li) + 4 * lg;
+            floatx4 acc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float x[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
-                if constexpr (edge) {
-                    const int n0 = 4 * (lane + 64 * u + 256 * it) - off;
+            for (int j = 0; j < 16; ++j) {
+                const float4 v = *(const float4 *)(col + 16 * j);
+                sxx = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, sxx))));
+                const float x[4] = {v.x, v.y, v.z, v.w};
+                const floatx4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] = (n0 + q >= 0 && n0 + q < N) ? x[q] : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    sx += x[q];
-                    sxx = fmaf(x[q], x[q], sxx);
-                }
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[b][q] = __builtin_elementwise_fma((floatx2){x[q], x[q]}, tw[b], acc[b][q]);
-                    const floatx2 t = tw[b];
-                    tw[b] = (floatx2){t.x * sb.step[b].x - t.y * sb.step[b].y, t.x * sb.step[b].y + t.y * sb.step[b].x};
-                }
+                for (int e = 0; e < 4; ++e)
+                    acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_tab[4 * j + e], x[e], j == 0 ? z : acc[e], 0, 0, 0);
+            }
+            const floatx4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);   // rows 4lg..4lg+3 of column 16g+li
+            // (cos-sum + i * minus-sin-sum) * exp(-i*theta*256*c)
+            xr[0] += t[0] * wc[g][0] - t[1] * ws[g][0];
+            xi[0] += t[0] * ws[g][0] + t[1] * wc[g][0];
+            if (lg < 3) {
+                xr[1] += t[2] * wc[g][1] - t[3] * ws[g][1];
+                xi[1] += t[2] * ws[g][1] + t[3] * wc[g][1];
+            } else {
+                xr[1] += t[2];                                     // row 14: sum of x
             }
         };
-        const int last = (nv - 1) / 256;
-        step(std::true_type{}, 0);
-        for (int it = 1; it < last; ++it) step(std::false_type{}, it);
-        if (last > 0) step(std::true_type{}, last);
-        // apply the in-float4 offsets, reduce over the wave
-        float mag2[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            float re = 0.f, im = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // (are + i*aim) * (rot.x + i*rot.y)
-                re += acc[b][q].x * sb.rot[b][q].x - acc[b][q].y * sb.rot[b][q].y;
-                im += acc[b][q].x * sb.rot[b][q].y + acc[b][q].y * sb.rot[b][q].x;
-            }
-            re = wave_sum_f(re);
-            im = wave_sum_f(im);
-            mag2[b] = re * re + im * im;
+        // ---- first half
+        if constexpr (P::G == 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::R1) : "memory");   // all but the second half's pieces
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flush();
+        fix_head(off);
+        if constexpr (P::G == 1) fix_tail(off);
+        group(std::integral_constant<int, 0>{});
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this half are done
+            fetch_begin();
+            next_off = f_off;
+            fetch_half(std::integral_constant<int, 0>{});
         }
-        sx = wave_sum_f(sx);
-        sxx = wave_sum_f(sxx);
-        if (lane == 0) {
-            float pmax = 0.f, psum = 0.f, rival = sx * sx;
+        // ---- second half
+        if constexpr (P::G == 2) {
+            if (more)
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // everything before the 16 pieces just issued
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fix_tail(off);
+            group(std::integral_constant<int, 1>{});
+            if (more) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                fetch_half(std::integral_constant<int, 1>{});
+            }
+        }
+        // ---- sums over the 16 columns (one DPP row per lane group), then over the wave
+        float m0 = row_sum(xr[0]), m1 = row_sum(xi[0]), m2 = row_sum(xr[1]), m3 = row_sum(xi[1]);
+        float sq = row_sum(sxx);
+        sq = lane_value(sq, 0) + lane_value(sq, 16) + lane_value(sq, 32) + lane_value(sq, 48);
+        const float e0 = m0 * m0 + m1 * m1, e1 = m2 * m2 + m3 * m3;   // |X|^2 of bins 2lg, 2lg+1
+        float mag2[SYNC_NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+        for (int b = 0; b < 7; ++b) mag2[b] = lane_value((b & 1) ? e1 : e0, 16 * (b >> 1));
+        const float sx = lane_value(m2, 48);
+        {
+            float pmax = 0.f, rival = sx * sx, known = 0.f;
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {
                 if (b < sb.n_ping) {
                     pmax = fmaxf(pmax, mag2[b]);
-                    psum += mag2[b];
                 } else if (b < sb.n_used) {
                     rival = fmaxf(rival, mag2[b]);
                 }
+                if (b < sb.n_bins) known += mag2[b];
             }
-            float known = psum + mag2[NB - 1];
-#pragma unroll
-            for (int b = 0; b < NB - 1; ++b)
-                if (b >= sb.n_ping && b < sb.n_used) known += mag2[b];
-            const float half = 0.5f * ((float)N * sxx - sx * sx);
+            const float half = 0.5f * ((float)N * sq - sx * sx);
             const float rest = fmaxf(half - known, 0.f);  // energy of the bins not computed
             const float margin = 1e-3f;
-            uint8_t v = 2;
-            if (sxx == 0.f) {
+            unsigned v = 2;
+            if (sq == 0.f) {
                 v = 0;  // silence: every bin is zero, the dominant bin is bin 0
             } else if (pmax > (fmaxf(rival, rest) + 1e-3f * half) * (1.f + margin)) {
                 v = 1;
@@ -170,21 +267,17 @@ __global__ __launch_bounds__(256, 3) void sync_kernel(const float *__restrict__ 
                        rest * (1.f - margin) - 1e-3f * half > pmax * (float)sb.others * (1.f + margin)) {
                 v = 0;
             }
-            ping_energy[w] = pmax;
-            win_energy[w] = sxx;
-            verdict[w] = v;
+            pend_pe = pmax;
+            pend_we = sq;
+            pend_v = v;
+            pend_w = w;
+            pend = true;
         }
+        off = next_off;
+        w = wn;
     }
-}
-
-static void fill_rot(SyncBins &sb, int slot, int bin, int N) {
-    sb.bin[slot] = bin;
-    const double a = 2.0 * M_PI * (double)(((long long)bin * 256) % N) / (double)N;
-    sb.step[slot] = make_float2((float)cos(a), (float)sin(a));
-    for (int q = 0; q < 4; ++q) {
-        const double aq = 2.0 * M_PI * (double)(((long long)bin * q) % N) / (double)N;
-        sb.rot[slot][q] = make_float2((float)cos(aq), (float)sin(aq));
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flush();
 }
 
 extern "C" int wn_sync_scan(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
@@ -211,40 +304,45 @@ extern "C" int wn_sync_scan(wn_ctx *ctx, const float *d_audio, int64_t audio_len
     memset(&sb, 0, sizeof(sb));
     sb.n_ping = n_ping;
     int slot = 0;
-    for (int k = ctx->ping_lo; k <= ctx->ping_hi; ++k) fill_rot(sb, slot++, k, N);
+    for (int k = ctx->ping_lo; k <= ctx->ping_hi; ++k) sb.bin[slot++] = k;
     // rivals: nearest bins of the separator, EOF and byte-0 tones (distinct from the ping bins)
     const double spacing = (double)ctx->s.sample_rate / (double)N;
     const int tones[3] = {ctx->s.sep_freq, ctx->s.eof_freq, ctx->s.base_freq};
-    for (int t = 0; t < 3 && slot < SYNC_NB - 1; ++t) {
+    for (int t = 0; t < 3 && slot < 6; ++t) {
         const int k = (int)llround((double)tones[t] / spacing);
         bool dup = k <= 0 || k >= ctx->nbins;
         for (int j = 0; j < slot; ++j) dup = dup || sb.bin[j] == k;
-        if (!dup) fill_rot(sb, slot++, k, N);
+        if (!dup) sb.bin[slot++] = k;
     }
     sb.n_used = slot;
-    const int nb = slot + 1;
-    fill_rot(sb, slot, (N - 1) / 2, N);  // last slot: the bin of [1, N/2] that argmax never sees
+    sb.bin[slot] = (N - 1) / 2;  // last slot: the bin of [1, N/2] that argmax never sees
+    sb.n_bins = slot + 1;
     sb.inv_n2 = (float)(2.0 / (double)N);
     // bins of [1, N/2) not computed: all but ping and rivals
     sb.others = (ctx->nbins - 1) - sb.n_used;
 
     const long long total = n_streams * n_windows;
     long long blocks = (total + 3) / 4;
-    const long long cap = (long long)ctx->num_cus * 8;
-    if (blocks > cap) blocks = cap;
-#define SYNC_LAUNCH(NBV)                                                                                         \
-    hipLaunchKernelGGL(sync_kernel<NBV>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_audio,     \
-                       (long long)audio_len, (long long)n_streams, (long long)stream_stride,                     \
-                       (long long)first_sample, (long long)n_windows, N, sb, d_ping_energy, d_win_energy, d_verdict)
-    switch (nb) {
-        case 2: SYNC_LAUNCH(2); break;
-        case 3: SYNC_LAUNCH(3); break;
-        case 4: SYNC_LAUNCH(4); break;
-        case 5: SYNC_LAUNCH(5); break;
-        case 6: SYNC_LAUNCH(6); break;
-        case 7: SYNC_LAUNCH(7); break;
-        default: SYNC_LAUNCH(8); break;
+    if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+    static bool attr_done[WN_MAX_DEVICES];
+    if (!attr_done[ctx->device]) {
+        WN_HIP_TRY(hipFuncSetAttribute((const void *)sync_kernel<7055>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)SyncPlan<7055>::LDS));
+        WN_HIP_TRY(hipFuncSetAttribute((const void *)sync_kernel<2205>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)SyncPlan<2205>::LDS));
+        attr_done[ctx->device] = true;
     }
-#undef SYNC_LAUNCH
+    if (N == 7055)
+        hipLaunchKernelGGL(sync_kernel<7055>, dim3((unsigned)blocks), dim3(256), SyncPlan<7055>::LDS,
+                           (hipStream_t)stream, d_audio, (long long)n_streams, (long long)stream_stride,
+                           (long long)first_sample, (long long)n_windows, sb, d_ping_energy, d_win_energy, d_verdict);
+    else if (N == 2205)
+        hipLaunchKernelGGL(sync_kernel<2205>, dim3((unsigned)blocks), dim3(256), SyncPlan<2205>::LDS,
+                           (hipStream_t)stream, d_audio, (long long)n_streams, (long long)stream_stride,
+                           (long long)first_sample, (long long)n_windows, sb, d_ping_energy, d_win_energy, d_verdict);
+    else {
+        wn_set_error("no sync kernel for windows of %d samples", N);
+        return WN_ERR_UNSUPPORTED;
+    }
     return wn_launch_check("sync_kernel");
 }
