@@ -2,8 +2,8 @@
 decoded frames.
 
 Streams never interact: rank r owns a contiguous block of stream indices and runs the whole
-encode/decode path on them with no data-path collective.  The only exchange is the gather
-of fixed-size decoded-frame records to one rank (RCCL over xGMI when the tensors live on
+encode/decode path on them with no data-path collective.  The only exchange is the collection
+of fixed-size decoded-frame records on one rank (RCCL over xGMI when the tensors live on
 GPUs, gloo on CPU tensors in the tests): 128 frame bytes + 8 bytes of parse record +
 4 bytes of length per stream, about 14 MB for 100 000 streams, latency-bound.
 """
@@ -51,8 +51,10 @@ def gather_records(packed: torch.Tensor, n_total: int, dst: int = 0):
     biggest = -(-n_total // world)
     pad = torch.zeros((biggest, RECORD_BYTES), dtype=torch.uint8, device=packed.device)
     pad[:packed.shape[0]] = packed
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
+    # an all-gather rather than a gather: the same bytes on the wire for rank dst, a ring
+    # collective every backend implements natively, and about 1.4 MB per rank per 10 000 streams
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
     if rank != dst:
         return None
     parts = []
