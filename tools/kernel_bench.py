@@ -6,6 +6,7 @@
   detect  K2  full-spectrum detection (f32 MFMA-bound)
   crc     K4  10 M frames, payload 0..107, 1 % corrupted, stride 128 (HBM-bound)
   long    C3  one 1-hour capture with AWGN: sync search + detection + slicing
+  protoA      the prototype scheme (2205-sample windows): synthesis + detection of 127-byte messages
 
 Usage: python tools/kernel_bench.py [--streams N] [--frames N] [--only name,...] [--reps R]
 """
@@ -52,7 +53,7 @@ def main():
     ap.add_argument("--streams", type=int, default=10000)
     ap.add_argument("--frames", type=int, default=10_000_000)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--only", default="synth,sync,detect,crc,long")
+    ap.add_argument("--only", default="synth,sync,detect,crc,long,protoA")
     args = ap.parse_args()
     only = set(args.only.split(","))
     m = M.Modem(M.esquema_b())
@@ -153,6 +154,28 @@ def main():
                     "audio_s_per_s": total / 44100 / mean * 1e3, "windows": nw, "calls": k,
                     "frames_recovered": len(ok), "frames_exact": int(sum(a == b for a, b in zip(ok, want))),
                     "frames_sent": nf, "refined": m.detect_stats()})
+
+    if "protoA" in only:
+        ma = M.Modem(M.esquema_a())
+        n, msg = 20000, 127
+        g = torch.Generator().manual_seed(4)
+        rows = torch.randint(0, 128, (n, 128), dtype=torch.uint8, generator=g).cuda()
+        lens_a = torch.full((n,), msg, dtype=torch.int32, device="cuda")
+        win_a = ma.esquema.win_n
+        stride_a = M.pad4((msg + 1) * win_a)
+        audio_a = torch.empty((n, stride_a), dtype=torch.float32, device="cuda")
+        mean_s, _ = timed(lambda: ma.encode_streams(rows, lens_a, stride_a, audio=audio_a), args.reps)
+        nw = stride_a // win_a
+        mean_d, _ = timed(lambda: ma.detect(audio_a, n, stride_a, nw), args.reps)
+        cls, _, _ = ma.detect(audio_a, n, stride_a, nw)
+        ok = bool(((cls[:, :msg] & 0x1FF).to(torch.uint8) == rows[:, :msg]).all())
+        n1, n2 = M.host_dft_plan(ma.esquema)
+        h1, h2 = n1 // 2 + 1, n2 // 2 + 1
+        flop = (2.0 * n1 * h2 * h2 * 2 + 2.0 * h1 * h2 * h1 * 4) * n * nw
+        out.append({"kernel": "prototype scheme: synth / detect_kernel<45,49>", "synth_ms": mean_s,
+                    "synth_GBps": n * stride_a * 4 / mean_s / 1e6, "detect_ms": mean_d,
+                    "detect_TFLOPs": flop / mean_d / 1e9, "detect_frac_f32_mfma": flop / mean_d / 1e9 / 157.3,
+                    "windows": n * nw, "bytes_exact": ok})
 
 
 if __name__ == "__main__":
