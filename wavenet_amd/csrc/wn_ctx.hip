@@ -199,16 +199,16 @@ int wn_device_check(const wn_ctx *ctx) {
 
 extern "C" int wn_ctx_destroy(wn_ctx *ctx) {
     if (!ctx) return WN_OK;
-    hipFree(ctx->d_sin_f32);
-    hipFree(ctx->d_sin_i16);
-    hipFree(ctx->d_tones);
-    hipFree(ctx->d_per_f32);
-    hipFree(ctx->d_per_i16);
-    hipFree(ctx->d_cls_lut);
-    hipFree(ctx->d_tw1);
-    hipFree(ctx->d_tw2);
-    hipFree(ctx->d_stats);
-    hipFree(ctx->d_crc_tab);
+    (void)hipFree(ctx->d_sin_f32);
+    (void)hipFree(ctx->d_sin_i16);
+    (void)hipFree(ctx->d_tones);
+    (void)hipFree(ctx->d_per_f32);
+    (void)hipFree(ctx->d_per_i16);
+    (void)hipFree(ctx->d_cls_lut);
+    (void)hipFree(ctx->d_tw1);
+    (void)hipFree(ctx->d_tw2);
+    (void)hipFree(ctx->d_stats);
+    (void)hipFree(ctx->d_crc_tab);
     free(ctx);
     return WN_OK;
 }
@@ -290,7 +290,7 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
             if (fq <= 0 || fq >= sr) continue;
             const int32_t period = sr / std::gcd(fq, sr);
             const int32_t stride = (period + 3 + 3) & ~3;
-            if (period > 4096 || pf.size() + (size_t)4 * stride > ((size_t)4 << 20)) continue;
+            if (stride > 4096 || pf.size() + (size_t)4 * stride > ((size_t)4 << 20)) continue;
             wn_tone t = {fq, period, stride, (int32_t)pf.size()};
             tones.push_back(t);
             for (int32_t r = 0; r < 4; ++r)

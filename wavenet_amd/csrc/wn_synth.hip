@@ -218,7 +218,15 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(const int32_t *__restr
 // Synthesis from period tables
 // ---------------------------------------------------------------------------------------
 #define SYN_MAX_TONES 320
+#define SYN_MAX_STRIDE 4096  // entries of one tone's table (period + wrap-around), see wn_ctx.hip
 
+// One workgroup owns a contiguous part of one frame's samples and goes through the segments
+// that overlap it.  The current segment's tone (one period plus three wrapped entries) sits
+// in LDS; the next segment's is fetched into registers while this one is written and goes to
+// the other LDS buffer afterwards, so a segment costs one barrier and no exposed latency.
+// Inside a segment a thread keeps its phase j and advances it by the workgroup's step modulo
+// the period; the four samples of an aligned vector are s[j..j+3].  Samples before the first
+// and after the last aligned vector of a segment are written one by one.
 template <typename T>
 __global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
     const int32_t *__restrict__ seg_start, const uint16_t *__restrict__ seg_freq, const int32_t *__restrict__ n_segs,
@@ -230,7 +238,9 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
     __shared__ uint16_t s_freq[SYN_MAX_SEGS];
     __shared__ uint16_t s_tone[SYN_MAX_SEGS];   // index into tones, 0xFFFF = not tabulated
     __shared__ wn_tone tones[SYN_MAX_TONES];
-    for (int i = threadIdx.x; i < n_tones; i += SYN_BLOCK) tones[i] = g_tones[i];
+    __shared__ __attribute__((aligned(16))) T s_per[2][SYN_MAX_STRIDE];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_tones; i += SYN_BLOCK) tones[i] = g_tones[i];
     const int sr = 4 * quarter;
     const float inv_sr = 1.0f / (float)sr;
     typedef typename Vec4<T>::type V4;
@@ -239,10 +249,10 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const long long f = item / parts;
         const int part = (int)(item - f * parts);
-        __syncthreads();  // descriptors ready / previous item's segment table no longer read
+        __syncthreads();  // descriptors ready / previous item's tables no longer read
         const int ns = n_segs[f];
-        for (int i = threadIdx.x; i <= ns; i += SYN_BLOCK) s_start[i] = seg_start[f * (long long)(seg_cap + 1) + i];
-        for (int i = threadIdx.x; i < ns; i += SYN_BLOCK) {
+        for (int i = tid; i <= ns; i += SYN_BLOCK) s_start[i] = seg_start[f * (long long)(seg_cap + 1) + i];
+        for (int i = tid; i < ns; i += SYN_BLOCK) {
             const int fq = seg_freq[f * (long long)seg_cap + i];
             int lo = 0, hi = n_tones;            // first descriptor with freq >= fq
             while (lo < hi) {
@@ -264,7 +274,8 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
         if (p1l > end) p1l = end;
         if (p0l >= p1l) continue;
         const int p0 = (int)p0l, p1 = (int)p1l;
-        const bool vec_ok = (((base + p0) & 3) == 0);
+        T *out = audio + base;
+        const int mis = (int)(base & 3);       // sample p is vector-aligned when (mis + p) % 4 == 0
 
         // first segment of this part: binary search (same result in every thread)
         int sg = ns;
@@ -276,80 +287,85 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
             }
             sg = lo;
         }
-        // this thread's current segment [lo, hi), kept in registers, and where in the tone's
-        // period its next vector starts (j), advanced by the thread's stride modulo the period
-        int lo = sg < ns ? s_start[sg] : total;
-        int hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
-        int fq = 0, period = 0, jstep = 0, j = 0;
-        const T *per = nullptr;      // copy 0 of the current tone, or null
-        int stride = 0;
-        bool fresh = true;           // segment changed: j must be computed, not advanced
-        for (int p = p0 + 4 * (int)threadIdx.x; p < p1; p += 4 * SYN_BLOCK) {
-            while (p >= hi) {
-                ++sg;
-                lo = hi;
-                hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
-                fresh = true;
+        int cur = 0;
+        if (sg < ns && s_tone[sg] != 0xFFFF) {
+            const wn_tone t = tones[s_tone[sg]];
+            const V4 *src = (const V4 *)(g_per + t.offset);
+            V4 *d = (V4 *)s_per[0];
+            for (int i = tid; i < (t.stride >> 2); i += SYN_BLOCK) d[i] = src[i];
+        }
+        __syncthreads();
+        while (sg < ns) {
+            const int lo = s_start[sg], hi = s_start[sg + 1];
+            if (lo >= p1) break;
+            const int a = lo > p0 ? lo : p0, b = hi < p1 ? hi : p1;
+            const int ti = s_tone[sg];
+            const int nx = sg + 1;
+            const int tn = (nx < ns && hi < p1) ? s_tone[nx] : 0xFFFF;
+            V4 pre0 = {}, pre1 = {};
+            int nv4 = 0;
+            if (tn != 0xFFFF) {                // next tone on its way while this one is written
+                const wn_tone t = tones[tn];
+                const V4 *src = (const V4 *)(g_per + t.offset);
+                nv4 = t.stride >> 2;
+                if (tid < nv4) pre0 = src[tid];
+                if (tid + SYN_BLOCK < nv4) pre1 = src[tid + SYN_BLOCK];
             }
-            T v[4];
-            if (sg >= ns) {                    // past the frame: zero fill
-                v[0] = v[1] = v[2] = v[3] = (T)0;
-            } else {
-                if (fresh) {
-                    fresh = false;
-                    fq = s_freq[sg];
-                    const int ti = s_tone[sg];
-                    if (ti != 0xFFFF) {
-                        const wn_tone t = tones[ti];
-                        period = t.period;
-                        stride = t.stride;
-                        per = g_per + t.offset;
-                        j = (int)((unsigned)(p - lo) % (unsigned)period);
-                        jstep = (4 * SYN_BLOCK) % period;
-                    } else {
-                        per = nullptr;
-                    }
-                } else if (per) {
-                    j += jstep;
-                    j = j >= period ? j - period : j;
-                }
-                if (per && p + 3 < hi) {       // four samples of one tabulated tone: one aligned load
-                    const int r = j & 3;
-                    const V4 o = *(const V4 *)(per + r * stride + (j - r));
-                    v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
-                } else {                       // another frequency, or a segment boundary inside the vector
-                    int sl = sg, ll = lo, hl = hi, fl = fq;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int pe = p + e;
-                        while (pe >= hl) {
-                            ++sl;
-                            ll = hl;
-                            hl = sl < ns ? s_start[sl + 1] : 0x7fffffff;
-                            fl = sl < ns ? s_freq[sl] : 0;
-                        }
-                        if (sl < ns) {
-                            const int m = mod_sr((unsigned)fl * (unsigned)(pe - ll), sr, inv_sr);
-                            const int half = 2 * quarter;
-                            const bool neg = m >= half;
-                            const int m2 = neg ? m - half : m;
-                            const T t = g_tab[m2 > quarter ? half - m2 : m2];
-                            v[e] = neg ? (T)(-t) : t;
-                        } else {
-                            v[e] = (T)0;
-                        }
+            if (ti != 0xFFFF) {
+                const int period = tones[ti].period;
+                const T *tab = s_per[cur];
+                int va = a + ((4 - ((mis + a) & 3)) & 3);
+                va = va > b ? b : va;
+                const int vb = va + ((b - va) & ~3);
+                int v = va + 4 * tid;
+                if (v < vb) {
+                    int j = (int)((unsigned)(v - lo) % (unsigned)period);
+                    const int jstep = (4 * SYN_BLOCK) % period;
+                    for (; v < vb; v += 4 * SYN_BLOCK) {
+                        V4 o;
+                        o.x = tab[j]; o.y = tab[j + 1]; o.z = tab[j + 2]; o.w = tab[j + 3];
+                        *(V4 *)(out + v) = o;
+                        j += jstep;
+                        j = j >= period ? j - period : j;
                     }
                 }
+                if (tid < 8) {                 // up to three samples before va and after vb
+                    const int pos = tid < 4 ? a + tid : vb + (tid - 4);
+                    const int lim = tid < 4 ? va : b;
+                    if (pos < lim) out[pos] = tab[(unsigned)(pos - lo) % (unsigned)period];
+                }
+            } else {                           // a frequency without a table: sample by sample
+                const int fq = s_freq[sg];
+                const int half = 2 * quarter;
+                for (int pos = a + tid; pos < b; pos += SYN_BLOCK) {
+                    const int m = mod_sr((unsigned)fq * (unsigned)(pos - lo), sr, inv_sr);
+                    const bool neg = m >= half;
+                    const int m2 = neg ? m - half : m;
+                    const T t = g_tab[m2 > quarter ? half - m2 : m2];
+                    out[pos] = neg ? (T)(-t) : t;
+                }
             }
-            T *dst = audio + base + p;
-            if (vec_ok && p + 4 <= p1) {
-                V4 o;
-                o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-                *(V4 *)dst = o;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (p + e < p1) dst[e] = v[e];
+            if (tn != 0xFFFF) {
+                V4 *d = (V4 *)s_per[cur ^ 1];
+                if (tid < nv4) d[tid] = pre0;
+                if (tid + SYN_BLOCK < nv4) d[tid + SYN_BLOCK] = pre1;
+            }
+            __syncthreads();  // next tone visible / everyone is done with this one
+            cur ^= 1;
+            sg = nx;
+        }
+        // past the frame: zero fill
+        const int a = total > p0 ? total : p0;
+        if (a < p1) {
+            int va = a + ((4 - ((mis + a) & 3)) & 3);
+            va = va > p1 ? p1 : va;
+            const int vb = va + ((p1 - va) & ~3);
+            V4 z = {};
+            for (int v = va + 4 * tid; v < vb; v += 4 * SYN_BLOCK) *(V4 *)(out + v) = z;
+            if (tid < 8) {
+                const int pos = tid < 4 ? a + tid : vb + (tid - 4);
+                const int lim = tid < 4 ? va : p1;
+                if (pos < lim) out[pos] = (T)0;
             }
         }
     }
@@ -421,12 +437,21 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     int per_cu = tabulated ? 2 : (int)((160 * 1024) / lds);
     if (per_cu > 2048 / SYN_BLOCK) per_cu = 2048 / SYN_BLOCK;
     if (per_cu < 1) per_cu = 1;
+    if (const char *e = getenv("WN_SYNTH_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 2048 / SYN_BLOCK) per_cu = v;
+    }
     const long long resident = (long long)ctx->num_cus * per_cu;
-    // Parts of 48 Ki samples (192 KB) and two workgroups per CU: consecutive workgroups then
-    // write consecutive pieces of HBM and the region being written at any time stays around
-    // 100 MB, which the memory system serves best (measured 4.0-5.1 TB/s over part sizes of
-    // 16 KB-1.5 MB and 1-4 workgroups per CU).  WN_SYNTH_PART overrides the size for tuning.
-    long long part_want = tabulated ? 49152 : 98304;
+    // Large parts amortise the per-part set-up (segment table, first tone): 192 Ki samples
+    // (768 KB) when there is enough work for every resident workgroup four times over, smaller
+    // ones (down to 16 Ki) when there are few frames.  Measured on 122 GB of output: 5.7-6.1
+    // TB/s for parts of 192 Ki..4 Mi samples and 1-3 workgroups per CU, 5.1 TB/s at 48 Ki.
+    // WN_SYNTH_PART / WN_SYNTH_PER_CU override the choice for tuning.
+    long long part_want = 98304;
+    if (tabulated) {
+        part_want = (n * slot_len / (resident * 4) + 4095) & ~4095ll;
+        part_want = part_want < 16384 ? 16384 : (part_want > 196608 ? 196608 : part_want);
+    }
     if (const char *e = getenv("WN_SYNTH_PART")) {
         const long long v = atoll(e);
         if (v >= 4096) part_want = v;
