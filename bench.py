@@ -11,6 +11,7 @@ scaling) and the decoded-frame records are gathered on rank 0 inside the timed r
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -178,8 +179,9 @@ def main():
         achieved = flop / (det_ms * 1e-3) / 1e12
         # HBM traffic of the detection launch from the committed PMC passes of this same command
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01d_pmc.json")
-        if os.path.exists(pmc_path):
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+        pmc_path = pmc_files[-1] if pmc_files else ""
+        if pmc_path:
             with open(pmc_path) as f:
                 pmc = json.load(f)["kernels"].get("detect_kernel<83, 85, false>", {})
             if "hbm_bytes" in pmc:
@@ -197,8 +199,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "detect_kernel<83,85> (+ float64 re-evaluation pass)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_source": "profiles/r01d_pmc.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + "
-                                           "WRITE_SIZE passes of this command, bytes per launch",
+                         "traffic_source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + "
+                                           "WRITE_SIZE passes of this command, bytes per launch" % os.path.basename(pmc_path),
                          "flop_per_window": detect_flop_per_window(n1, n2), "windows_per_launch": win_per_launch,
                          "ms_per_launch": det_ms},
             "synth": {"bound": "hbm", "ms_per_launch": syn_ms,
