@@ -7,12 +7,14 @@
 // Every tone restarts at t = 0 and every frequency is a whole number of Hz, so sample i
 // of a tone of f Hz is amp*sin(2*pi*((f*i) mod sr)/sr): an exact table lookup in one
 // quarter period of sr entries (built on the host in float64, so each output sample is
-// the correctly rounded value).  The kernel is HBM-write-bound: 4 bytes (float) or
+// the correctly rounded value).  The kernels are HBM-write-bound: 4 bytes (float) or
 // 2 bytes (int16) per sample out, nothing but the ~1.5 KB segment table per frame in.
 //
-// Layout: one workgroup owns a contiguous part of one frame's samples.  It keeps the
-// quarter-wave table (sr/4+1 entries) and the frame's segment table in LDS, finds its
-// first segment once, and then every thread writes 4 consecutive samples per step.
+// Layout: one workgroup owns a contiguous part of one frame's samples, keeps the frame's
+// segment table in LDS, finds its first segment once, and every thread writes 4 consecutive
+// samples per step.  synth_period_kernel serves the tones of the scheme from one-period
+// tables (the period of an f-Hz tone is sr/gcd(f, sr) samples); synth_kernel looks every
+// sample up in the quarter-wave table held in LDS and serves contexts without period tables.
 #include <stdlib.h>
 
 #include "wn_common.h"
