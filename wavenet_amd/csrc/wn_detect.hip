@@ -57,6 +57,7 @@
 #include "wn_dma.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 #define FLAG_TOP2 (1 << 30)
 #define FLAG_FULL (1 << 29)
@@ -121,7 +122,7 @@ struct Plan {
 // low 12 bits replaced by the bin: keys order like the values (to 2^-11), ties by bin.
 struct Top3 {
     unsigned k1, k2, k3;
-    float mx;   // exact largest value
+    unsigned mx;   // bit pattern of the exact largest value (non-negative floats order like their bits)
 };
 __device__ __forceinline__ void top3_insert(Top3 &t, unsigned key) {
     t.k3 = max(t.k3, min(key, t.k2));
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // ------------------------------------------------------------------ stage 2
         Top3 best;
         best.k1 = best.k2 = best.k3 = 0u;
-        best.mx = 0.f;
+        best.mx = 0u;
         static_for<TA>([&](auto TT) {
             constexpr int tt = decltype(TT)::value;
             uint4 epa[4];
@@ -438,23 +439,29 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
 #pragma unroll
                 for (int c = 0; c < C2T; ++c) after_drain(acc[i][c]);
             __builtin_amdgcn_sched_barrier(0);
-            // arg-max work of the tile: two outputs per accumulator element
-            static_for<4>([&](auto R) {
+            // arg-max work of the tile: two outputs per accumulator element; the float part on
+            // register pairs (packed f32 instructions), the keys one by one
+            static_for<2>([&](auto HALF) {
                 static_for<C2T>([&](auto C) {
-                    constexpr int r = decltype(R)::value, c = decltype(C)::value;
-                    const float A = acc[0][c][r], B = acc[1][c][r], Cc = acc[2][c][r], E = acc[3][c][r];
-                    const float rp = A + B, rm = A - B, ip = Cc - E, im = Cc + E;
-                    float mp = rp * rp + ip * ip, mm = rm * rm + im * im;
-                    const unsigned tp = c == 0 ? epa[r].x : (c == 1 ? epa[r].z : (c == 2 ? epb[r].x : 0u));
-                    const unsigned tm = c == 0 ? epa[r].y : (c == 1 ? epa[r].w : (c == 2 ? epb[r].y : 0u));
-                    // outputs that must not compete although their value is not zero: known positions
-                    constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
-                    if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
-                    if constexpr (c == 0 || (tt == 0 && r == 0) || (xhere && P::XMINUS))
-                        mm = __builtin_unpredictable(tm & EP_UNUSED) ? 0.f : mm;
-                    best.mx = fmaxf(best.mx, fmaxf(mp, mm));
-                    top3_insert(best, (__float_as_uint(mp) & ~KEY_BIN) | tp);
-                    top3_insert(best, (__float_as_uint(mm) & ~KEY_BIN) | tm);
+                    constexpr int hf = decltype(HALF)::value, c = decltype(C)::value;
+                    const floatx2 A = hf ? acc[0][c].hi : acc[0][c].lo, B = hf ? acc[1][c].hi : acc[1][c].lo;
+                    const floatx2 Cc = hf ? acc[2][c].hi : acc[2][c].lo, E = hf ? acc[3][c].hi : acc[3][c].lo;
+                    const floatx2 rp = A + B, rm = A - B, ip = Cc - E, im = Cc + E;
+                    const floatx2 mp2 = rp * rp + ip * ip, mm2 = rm * rm + im * im;
+                    static_for<2>([&](auto EL) {
+                        constexpr int r = 2 * hf + decltype(EL)::value;
+                        float mp = mp2[decltype(EL)::value], mm = mm2[decltype(EL)::value];
+                        const unsigned tp = c == 0 ? epa[r].x : (c == 1 ? epa[r].z : (c == 2 ? epb[r].x : 0u));
+                        const unsigned tm = c == 0 ? epa[r].y : (c == 1 ? epa[r].w : (c == 2 ? epb[r].y : 0u));
+                        // outputs that must not compete although their value is not zero: known positions
+                        constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
+                        if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
+                        if constexpr (c == 0 || (tt == 0 && r == 0) || (xhere && P::XMINUS))
+                            mm = __builtin_unpredictable(tm & EP_UNUSED) ? 0.f : mm;
+                        best.mx = max(best.mx, max(__float_as_uint(mp), __float_as_uint(mm)));
+                        top3_insert(best, (__float_as_uint(mp) & ~KEY_BIN) | tp);
+                        top3_insert(best, (__float_as_uint(mm) & ~KEY_BIN) | tm);
+                    });
                 });
             });
         });
@@ -463,15 +470,15 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // sixteens merge two disjoint lane sets each and leave every lane of a row with the
         // row's result; two row broadcasts then collect the four rows in the last row (the
         // other rows merge with themselves and are not used).  Lane 63 decides and stores.
-        auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, float om) {
-            best.mx = fmaxf(best.mx, om);
+        auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, unsigned om) {
+            best.mx = max(best.mx, om);
             top3_insert(best, o1);
             top3_insert(best, o2);
             top3_insert(best, o3);
         };
 #define WN_MERGE_DPP(CTRL, ROWS)                                                                        \
     merge_with(dpp_u<CTRL, ROWS>(best.k1), dpp_u<CTRL, ROWS>(best.k2), dpp_u<CTRL, ROWS>(best.k3),     \
-               __uint_as_float(dpp_u<CTRL, ROWS>(__float_as_uint(best.mx))))
+               dpp_u<CTRL, ROWS>(best.mx))
         WN_MERGE_DPP(0xB1, 0xF);    // quad_perm [1,0,3,2]
         WN_MERGE_DPP(0x4E, 0xF);    // quad_perm [2,3,0,1]
         WN_MERGE_DPP(0x141, 0xF);   // row_half_mirror
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         WN_MERGE_DPP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
 #undef WN_MERGE_DPP
         {
-            const bool silent = best.mx <= 0.f;   // every bin is zero: np.argmax gives bin 0
+            const bool silent = best.mx == 0u;   // every bin is zero: np.argmax gives bin 0
             const float f1 = __uint_as_float(best.k1 & ~KEY_BIN), f2 = __uint_as_float(best.k2 & ~KEY_BIN),
                         f3 = __uint_as_float(best.k3 & ~KEY_BIN);
             const bool full = f3 >= f1 * keep, top2 = f2 >= f1 * keep;
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             const unsigned cls = lut_s[b];
             pend_bin = silent ? 0 : (full ? (b | FLAG_FULL) : (top2 ? (b | FLAG_TOP2) : b));
             pend_cls = silent ? cls : (full ? 0u : (top2 ? (best.k2 & KEY_BIN) : cls));
-            pend_mag = sqrtf(best.mx);
+            pend_mag = sqrtf(__uint_as_float(best.mx));
             pend_w = w;
             pend = true;
         }
