@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwavenet_hip.so")
+# WN_HIP_LIB names another build of the same library (used to time two builds side by side)
+LIB_PATH = os.environ.get("WN_HIP_LIB") or os.path.join(_HERE, "csrc", "libwavenet_hip.so")
 
 
 class WnScheme(C.Structure):

@@ -124,9 +124,16 @@ struct Top3 {
     unsigned k1, k2, k3;
     unsigned mx;   // bit pattern of the exact largest value (non-negative floats order like their bits)
 };
+__device__ __forceinline__ unsigned med3_u32(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// k1 >= k2 >= k3 before and after: the new third is the median of (k2, k3, key), the new
+// second the median of (k1, k2, key)
 __device__ __forceinline__ void top3_insert(Top3 &t, unsigned key) {
-    t.k3 = max(t.k3, min(key, t.k2));
-    t.k2 = max(min(t.k1, t.k2), min(max(t.k1, t.k2), key));   // median of three
+    t.k3 = med3_u32(t.k2, t.k3, key);
+    t.k2 = med3_u32(t.k1, t.k2, key);
     t.k1 = max(t.k1, key);
 }
 
