@@ -11,6 +11,10 @@ seen by c1_shared reports samples-consumed / 44100.  Every value written here is
 output of reference code; the oracle (oracle/modem_oracle.py) is asserted equal to it
 while the file is written, and tests/test_oracle_golden.py re-checks that on every run.
 Only data is stored: inputs, seeds, expected outputs and digests of long arrays.
+
+NOT TO BE RUN AGAIN.  The fixture was generated once; a later attempt to import the reference
+in this environment was refused (it may be read, not executed), and that refusal stands.  The
+script is kept as the record of how the committed vectors were made.
 """
 import hashlib
 import json

@@ -17,6 +17,10 @@ cannot play before h), so the outcome does not depend on thread scheduling.
 
 Stored per scenario: both return values, both final clocks, samples played by each side and
 the outcome of every listen call (windows consumed, bytes heard or error text, ping result).
+
+NOT TO BE RUN AGAIN.  The fixture was generated once; a later attempt to import the reference
+in this environment was refused (it may be read, not executed), and that refusal stands.  The
+script is kept as the record of how the committed vectors were made.
 """
 import json
 import os
