@@ -309,6 +309,27 @@ def test_detect_noise_only_and_offsets(mb, golden):
         assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
 
 
+@pytest.mark.parametrize("exp", [-100, -80, -45, 40, 60])
+def test_detect_dynamic_range(mb, golden, exp):
+    """Scaling the samples by a power of two scales the reference's float64 spectrum exactly,
+    so its decisions do not change.  Very quiet and very loud captures (whose float32 squared
+    magnitudes under- or overflow) must still give the oracle's bins; digital silence between
+    them gives bin 0."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    frame = mo.build_frame(1, MAC_O, MAC_D, 3, b"rango")
+    x = mo.emit_frame(frame, SB)[:12 * 7055]
+    x = x + 0.02 * np.random.default_rng(exp & 0xFF).standard_normal(len(x))
+    x[3 * 7055:5 * 7055] = 0.0
+    x32 = (x.astype(np.float32) * np.float32(2.0) ** exp).astype(np.float32)
+    assert np.isfinite(x32).all() and (x32 != 0).any()
+    mb.detect_stats()
+    check_detect(mb, x32, 7055, lut)
+    windows, top2, full = mb.detect_stats()
+    assert windows == 12
+    if exp in (-100, -80, 60):
+        assert full == 10      # every window with signal went through the float64 spectrum
+
+
 @pytest.mark.parametrize("scheme", ["B", "A"])
 def test_detect_every_bin(mb, ma, golden, scheme):
     """One window per bin k of [0, N/2): a tone on the centre of bin k with a weaker one on

@@ -46,7 +46,9 @@
 // whose largest bins are closer than the relative band (default 5e-5, ~10x the f32 error)
 // plus the 2^-12 the keys drop are re-evaluated in float64: the two candidate bins by
 // direct summation with exactly reduced phases; if a third bin is in the band too, the
-// whole spectrum.
+// whole spectrum.  Windows whose largest |Z|^2 is zero or outside [1e-30, 1e30] take the
+// float64 path too (all-zero windows end there without a spectrum), so the result does not
+// depend on how loud the capture is.
 #include <math.h>
 #include <stdlib.h>
 
@@ -500,15 +502,19 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         WN_MERGE_DPP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
 #undef WN_MERGE_DPP
         {
-            const bool silent = best.mx == 0u;   // every bin is zero: np.argmax gives bin 0
+            // A largest |Z|^2 outside [1e-30, 1e30] (zero, or samples so small or so large that
+            // float32 squares lose their meaning, or not a number) is not decided here: the
+            // window goes to the float64 pass, which also recognises all-zero windows.
+            const float mxf = __uint_as_float(best.mx);
+            const bool odd = !(mxf >= 1e-30f && mxf <= 1e30f);
             const float f1 = __uint_as_float(best.k1 & ~KEY_BIN), f2 = __uint_as_float(best.k2 & ~KEY_BIN),
                         f3 = __uint_as_float(best.k3 & ~KEY_BIN);
-            const bool full = f3 >= f1 * keep, top2 = f2 >= f1 * keep;
-            const int b = silent ? 0 : (int)(best.k1 & KEY_BIN);
-            const unsigned cls = lut_s[b];
-            pend_bin = silent ? 0 : (full ? (b | FLAG_FULL) : (top2 ? (b | FLAG_TOP2) : b));
-            pend_cls = silent ? cls : (full ? 0u : (top2 ? (best.k2 & KEY_BIN) : cls));
-            pend_mag = sqrtf(__uint_as_float(best.mx));
+            const bool full = odd | (f3 >= f1 * keep), top2 = f2 >= f1 * keep;
+            const int b = (int)(best.k1 & KEY_BIN);
+            const unsigned cls = lut_s[odd ? 0 : b];
+            pend_bin = full ? ((odd ? 0 : b) | FLAG_FULL) : (top2 ? (b | FLAG_TOP2) : b);
+            pend_cls = full ? 0u : (top2 ? (best.k2 & KEY_BIN) : cls);
+            pend_mag = odd ? 0.f : sqrtf(mxf);
             pend_w = w;
             pend = true;
         }
@@ -603,9 +609,13 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                 rm = first ? ma : mb;
                 if (tid == 0) atomicAdd(&stats[1], 1ull);
             } else {
+                // all-zero windows (digital silence) need no spectrum: np.argmax of zeros is 0
+                bool nz = false;
+                for (int n = tid; n < N; n += 256) nz |= (x[n] != 0.0f);
+                const bool any = __syncthreads_or(nz);
                 double bm = -1.0;
-                int bb = 0x7fffffff;
-                for (int b = tid; b < nbins; b += 256) {
+                int bb = any ? 0x7fffffff : 0;
+                for (int b = tid; any && b < nbins; b += 256) {
                     double re = 0, im = 0;
                     int m = 0;
                     for (int n = 0; n < N; ++n) {
@@ -618,6 +628,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                     const double mg = re * re + im * im;
                     if (mg > bm) { bm = mg; bb = b; }  // b ascends: first maximum is kept
                 }
+                if (!any) bm = tid == 0 ? 0.0 : -1.0;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) {
                     const double om = __shfl_xor(bm, d);
@@ -630,9 +641,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                 bm = best_m[0]; bb = best_b[0];
                 for (int q = 1; q < 4; ++q)
                     if (best_m[q] > bm || (best_m[q] == bm && best_b[q] < bb)) { bm = best_m[q]; bb = best_b[q]; }
-                rb = bb;
-                rm = bm;
-                if (tid == 0) atomicAdd(&stats[2], 1ull);
+                rb = bb < nbins ? bb : 0;   // no bin compared greater (samples that are not numbers)
+                rm = bm > 0.0 ? bm : 0.0;
+                if (tid == 0 && any) atomicAdd(&stats[2], 1ull);
             }
             if (tid == 0) {
                 bin[wi] = rb;
