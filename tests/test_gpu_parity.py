@@ -470,6 +470,15 @@ def test_sync_scan_energies_and_sound_verdicts(mb, golden):
             assert (vd != 2).mean() > 0.9           # clean frames are decided without a spectrum
     sil = torch.zeros(7056 * 3, dtype=torch.float32, device="cuda")
     assert mb.sync_scan(sil, 1, 7056 * 3, 3)[2].cpu().tolist() == [[0, 0, 0]]
+    # far outside the float32 energy range nothing is decided wrongly: undecided, or silence
+    x = capture_of(golden["listen_b"][1]).astype(np.float32)[:8 * 7055]
+    is_ping = (lut[mo.window_bins(x.astype(np.float64), 7055)[0]] & 512) != 0
+    for exp in (-100, -70, 58):
+        pad = np.zeros(M.pad4(8 * 7055 + 7055), dtype=np.float32)
+        pad[:8 * 7055] = x * np.float32(2.0) ** exp
+        vd = mb.sync_scan(dev(pad), 1, len(pad), 9)[2].cpu().numpy()[0]
+        assert np.all(is_ping[vd[:8] == 1]) and not np.any(is_ping[vd[:8] == 0])
+        assert vd[8] == 0
 
 
 # ------------------------------------------------------------------------------- round trip at scale

@@ -259,8 +259,18 @@ __global__ __launch_bounds__(256, 1) void sync_kernel(const float *__restrict__ 
             const float rest = fmaxf(half - known, 0.f);  // energy of the bins not computed
             const float margin = 1e-3f;
             unsigned v = 2;
-            if (sq == 0.f) {
-                v = 0;  // silence: every bin is zero, the dominant bin is bin 0
+            const float tot = (float)N * sq;
+            if (!(tot >= 1e-28f && tot <= 1e30f)) {
+                // Silence, or too quiet / too loud for float32 energies.  The bin sums themselves
+                // (not squared) tell the two apart well enough: if every ping bin is exactly
+                // zero the dominant bin is not a ping bin (silence gives bin 0); anything else
+                // is left to the spectrum.
+                const float l0 = fabsf(m0) + fabsf(m1), l1 = fabsf(m2) + fabsf(m3);
+                float plin = 0.f;
+#pragma unroll
+                for (int b = 0; b < 7; ++b)
+                    if (b < sb.n_ping) plin += lane_value((b & 1) ? l1 : l0, 16 * (b >> 1));
+                v = plin == 0.f ? 0 : 2;
             } else if (pmax > (fmaxf(rival, rest) + 1e-3f * half) * (1.f + margin)) {
                 v = 1;
             } else if (rival > pmax * (1.f + margin) ||
