@@ -5,13 +5,6 @@
 
 #include "wavenet_hip.h"
 
-struct wn_tone {
-    int32_t freq;      // Hz
-    int32_t period;    // samples
-    int32_t stride;    // elements per rotated copy, a multiple of 4, >= period + 3
-    int32_t offset;    // first element of copy 0; copy r starts at offset + r*stride
-};
-
 struct wn_ctx {
     wn_scheme s;
     int device;
@@ -20,13 +13,6 @@ struct wn_ctx {
     int32_t quarter;
     float *d_sin_f32;
     int16_t *d_sin_i16;
-    // synthesis: one period of every tone the scheme emits (a whole-Hz tone that restarts
-    // at t = 0 repeats every sr/gcd(f, sr) samples), four copies per tone rotated by
-    // 0..3 samples so that any four consecutive samples are one aligned vector load
-    int32_t n_tones;
-    wn_tone *d_tones;      // sorted by frequency
-    float *d_per_f32;
-    int16_t *d_per_i16;
     // detection: window length n = n1*n2 (coprime, n2 odd), CRT idempotents e1, e2
     int32_t n, n1, n2, nbins;
     int32_t e1, e2;

@@ -201,9 +201,6 @@ extern "C" int wn_ctx_destroy(wn_ctx *ctx) {
     if (!ctx) return WN_OK;
     (void)hipFree(ctx->d_sin_f32);
     (void)hipFree(ctx->d_sin_i16);
-    (void)hipFree(ctx->d_tones);
-    (void)hipFree(ctx->d_per_f32);
-    (void)hipFree(ctx->d_per_i16);
     (void)hipFree(ctx->d_cls_lut);
     (void)hipFree(ctx->d_tw1);
     (void)hipFree(ctx->d_tw2);
@@ -273,42 +270,6 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
         wn_host_sine_tables(s, f.data(), h.data(), ctx->quarter + 1);
         INIT_TRY(upload(&ctx->d_sin_f32, f.data(), f.size()));
         INIT_TRY(upload(&ctx->d_sin_i16, h.data(), h.size()));
-        // period tables of the scheme's own tones (other frequencies are synthesised sample
-        // by sample from the quarter-wave table)
-        std::vector<int32_t> freqs;
-        for (int32_t b = 0; b <= s->max_byte; ++b) freqs.push_back(s->base_freq + b * s->freq_step);
-        freqs.push_back(s->sep_freq);
-        freqs.push_back(s->ping_freq);
-        freqs.push_back(s->eof_freq);
-        std::sort(freqs.begin(), freqs.end());
-        freqs.erase(std::unique(freqs.begin(), freqs.end()), freqs.end());
-        const int32_t sr = s->sample_rate, q = ctx->quarter, half = 2 * q;
-        std::vector<wn_tone> tones;
-        std::vector<float> pf;
-        std::vector<int16_t> ph;
-        for (int32_t fq : freqs) {
-            if (fq <= 0 || fq >= sr) continue;
-            const int32_t period = sr / std::gcd(fq, sr);
-            const int32_t stride = (period + 3 + 3) & ~3;
-            if (stride > 4096 || pf.size() + (size_t)4 * stride > ((size_t)4 << 20)) continue;
-            wn_tone t = {fq, period, stride, (int32_t)pf.size()};
-            tones.push_back(t);
-            for (int32_t r = 0; r < 4; ++r)
-                for (int32_t i = 0; i < stride; ++i) {
-                    const int32_t m = (int32_t)(((int64_t)fq * ((i + r) % period)) % sr);
-                    const bool neg = m >= half;
-                    const int32_t m2 = neg ? m - half : m;
-                    const int32_t idx = m2 > q ? half - m2 : m2;
-                    pf.push_back(neg ? -f[idx] : f[idx]);
-                    ph.push_back(neg ? (int16_t)(-h[idx]) : h[idx]);
-                }
-        }
-        ctx->n_tones = (int32_t)tones.size();
-        if (ctx->n_tones > 0) {
-            INIT_TRY(upload(&ctx->d_tones, tones.data(), tones.size()));
-            INIT_TRY(upload(&ctx->d_per_f32, pf.data(), pf.size()));
-            INIT_TRY(upload(&ctx->d_per_i16, ph.data(), ph.size()));
-        }
     }
     {
         std::vector<uint16_t> lut(ctx->nbins);

@@ -11,10 +11,8 @@
 // 2 bytes (int16) per sample out, nothing but the ~1.5 KB segment table per frame in.
 //
 // Layout: one workgroup owns a contiguous part of one frame's samples, keeps the frame's
-// segment table in LDS, finds its first segment once, and every thread writes 4 consecutive
-// samples per step.  synth_period_kernel serves the tones of the scheme from one-period
-// tables (the period of an f-Hz tone is sr/gcd(f, sr) samples); synth_kernel looks every
-// sample up in the quarter-wave table held in LDS and serves contexts without period tables.
+// segment table and the quarter-wave table in LDS, finds its first segment once, and every
+// thread writes 4 consecutive samples per step from a one-period table of the segment's tone.
 #include <stdlib.h>
 
 #include "wn_common.h"
@@ -100,169 +98,76 @@ __device__ __forceinline__ int mod_sr(unsigned x, int sr, float inv_sr) {
     return r;
 }
 
-// LDS position of table entry i.  Lanes of a wave read entries f*4 apart (mod sr); for the
-// many tones whose 4*f is a multiple of 32 that is one bank for the whole wave, so the low
-// five bits are XOR-ed with the next two groups of five (a bijection inside each 32-entry row).
+// LDS position of quarter-wave table entry i.  Lanes of a wave read entries f*4 apart (mod sr);
+// for the many tones whose 4*f is a multiple of 32 that is one bank for the whole wave, so the
+// low five bits are XOR-ed with the next two groups of five (a bijection inside each 32-entry row).
 __device__ __forceinline__ int tab_pos(int i) { return i ^ (((i >> 5) ^ (i >> 10)) & 31); }
 
-template <typename T>
-__device__ __forceinline__ T sine_lookup(const T *tab, int m, int quarter) {
-    const int half = 2 * quarter;
-    const bool neg = m >= half;
-    const int m2 = neg ? m - half : m;
-    const int idx = m2 > quarter ? half - m2 : m2;
-    const T v = tab[tab_pos(idx)];
-    return neg ? (T)(-v) : v;
-}
-
-template <typename T>
-__global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(const int32_t *__restrict__ seg_start,
-                                                          const uint16_t *__restrict__ seg_freq,
-                                                          const int32_t *__restrict__ n_segs, int seg_cap,
-                                                          long long n_frames, int parts, int part_len,
-                                                          const long long *__restrict__ dst_off,
-                                                          const long long *__restrict__ fill_to,
-                                                          T *__restrict__ audio, long long audio_len,
-                                                          const T *__restrict__ g_tab, int quarter) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int32_t *s_start = (int32_t *)smem;                                   // SYN_MAX_SEGS+1
-    uint16_t *s_freq = (uint16_t *)(smem + (SYN_MAX_SEGS + 1) * 4);       // SYN_MAX_SEGS
-    T *tab = (T *)(smem + (SYN_MAX_SEGS + 1) * 4 + SYN_MAX_SEGS * 2 + 8); // quarter+1 rounded up to 32
-    for (int i = threadIdx.x; i <= quarter; i += SYN_BLOCK) tab[tab_pos(i)] = g_tab[i];
-    const int sr = 4 * quarter;
-    const float inv_sr = 1.0f / (float)sr;
-    typedef typename Vec4<T>::type V4;
-
-    const long long n_items = n_frames * parts;
-    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const long long f = item / parts;
-        const int part = (int)(item - f * parts);
-        __syncthreads();  // table ready / previous item's segment table no longer read
-        const int ns = n_segs[f];
-        for (int i = threadIdx.x; i <= ns; i += SYN_BLOCK) s_start[i] = seg_start[f * (long long)(seg_cap + 1) + i];
-        for (int i = threadIdx.x; i < ns; i += SYN_BLOCK) s_freq[i] = seg_freq[f * (long long)seg_cap + i];
-        __syncthreads();
-        const int total = s_start[ns];
-        long long end = fill_to ? fill_to[f] : (long long)total;
-        if (end < total) end = total;
-        const long long base = dst_off[f];
-        if (base < 0) continue;                              // never write outside the buffer
-        if (base + end > audio_len) end = audio_len - base;
-        const long long p0l = (long long)part * part_len;
-        long long p1l = p0l + part_len;
-        if (p1l > end) p1l = end;
-        if (p0l >= p1l) continue;
-        const int p0 = (int)p0l, p1 = (int)p1l;
-        const bool vec_ok = (((base + p0) & 3) == 0);
-
-        // first segment of this part: binary search (same result in every thread)
-        int sg = ns;
-        if (p0 < total) {
-            int lo = 0, hi = ns - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_start[mid] <= p0) lo = mid; else hi = mid - 1;
-            }
-            sg = lo;
-        }
-        // this thread's current segment [lo, hi) and its frequency, kept in registers
-        int lo = sg < ns ? s_start[sg] : total;
-        int hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
-        int fq = sg < ns ? s_freq[sg] : 0;
-        for (int p = p0 + 4 * (int)threadIdx.x; p < p1; p += 4 * SYN_BLOCK) {
-            while (p >= hi) {
-                ++sg;
-                lo = hi;
-                hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
-                fq = sg < ns ? s_freq[sg] : 0;
-            }
-            T v[4];
-            if (sg >= ns) {                    // past the frame: zero fill
-                v[0] = v[1] = v[2] = v[3] = (T)0;
-            } else if (p + 3 < hi) {           // all four samples in one segment
-                int m = mod_sr((unsigned)fq * (unsigned)(p - lo), sr, inv_sr);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = sine_lookup(tab, m, quarter);
-                    m += fq;
-                    m = m >= sr ? m - sr : m;
-                }
-            } else {                           // a segment boundary inside the float4
-                int sl = sg, ll = lo, hl = hi, fl = fq;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int pe = p + e;
-                    while (pe >= hl) {
-                        ++sl;
-                        ll = hl;
-                        hl = sl < ns ? s_start[sl + 1] : 0x7fffffff;
-                        fl = sl < ns ? s_freq[sl] : 0;
-                    }
-                    v[e] = sl < ns ? sine_lookup(tab, mod_sr((unsigned)fl * (unsigned)(pe - ll), sr, inv_sr), quarter)
-                                   : (T)0;
-                }
-            }
-            T *dst = audio + base + p;
-            if (vec_ok && p + 4 <= p1) {
-                V4 o;
-                o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-                *(V4 *)dst = o;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (p + e < p1) dst[e] = v[e];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Synthesis from period tables
-// ---------------------------------------------------------------------------------------
-#define SYN_MAX_TONES 320
-#define SYN_MAX_STRIDE 4096  // entries of one tone's table (period + wrap-around), see wn_ctx.hip
+#define SYN_MAX_STRIDE 2304  // longest tone period kept as a table: 2301 samples + 3 wrapped entries
+#define SYN_OFF_FREQ (((SYN_MAX_SEGS + 1) * 4 + 15) & ~15)
+#define SYN_OFF_PERIOD (SYN_OFF_FREQ + SYN_MAX_SEGS * 2)
+#define SYN_OFF_TAB (SYN_OFF_PERIOD + SYN_MAX_SEGS * 2)
 
 // One workgroup owns a contiguous part of one frame's samples and goes through the segments
-// that overlap it.  The current segment's tone (one period plus three wrapped entries) sits
-// in LDS; the next segment's is fetched into registers while this one is written and goes to
-// the other LDS buffer afterwards, so a segment costs one barrier and no exposed latency.
-// Inside a segment a thread keeps its phase j and advances it by the workgroup's step modulo
-// the period; the four samples of an aligned vector are s[j..j+3].  Samples before the first
-// and after the last aligned vector of a segment are written one by one.
+// that overlap it.  LDS holds the quarter-wave table, the frame's segment table and two
+// buffers of one tone period each.  A tone of f Hz repeats every sr/gcd(f, sr) samples: the
+// period of the current segment's tone (plus three wrapped entries) sits in one buffer, the
+// next segment's is built from the quarter-wave table into the other before this segment is
+// written, so a segment costs one barrier, and the steady state issues no global loads at all
+// (a wait for a load would also wait for every store issued before it).  Inside a segment a
+// thread keeps its phase j and advances it by the workgroup's step modulo the period; the four
+// samples of an aligned vector are s[j..j+3].  Samples before the first and after the last
+// aligned vector of a segment are written one by one.  Segments shorter than four periods (and
+// tones whose period does not fit a buffer) take their samples straight from the quarter-wave
+// table.
 template <typename T>
-__global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
+__global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
     const int32_t *__restrict__ seg_start, const uint16_t *__restrict__ seg_freq, const int32_t *__restrict__ n_segs,
     int seg_cap, long long n_frames, int parts, int part_len, const long long *__restrict__ dst_off,
     const long long *__restrict__ fill_to, T *__restrict__ audio, long long audio_len,
-    const T *__restrict__ g_tab, int quarter, const wn_tone *__restrict__ g_tones, int n_tones,
-    const T *__restrict__ g_per) {
-    __shared__ int32_t s_start[SYN_MAX_SEGS + 1];
-    __shared__ uint16_t s_freq[SYN_MAX_SEGS];
-    __shared__ uint16_t s_tone[SYN_MAX_SEGS];   // index into tones, 0xFFFF = not tabulated
-    __shared__ wn_tone tones[SYN_MAX_TONES];
-    __shared__ __attribute__((aligned(16))) T s_per[2][SYN_MAX_STRIDE];
+    const T *__restrict__ g_tab, int quarter, int tab_entries) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int32_t *s_start = (int32_t *)smem;                        // SYN_MAX_SEGS + 1
+    uint16_t *s_freq = (uint16_t *)(smem + SYN_OFF_FREQ);      // frequency mod sr
+    uint16_t *s_period = (uint16_t *)(smem + SYN_OFF_PERIOD);  // period of the tone, 0 = no table
+    T *tab = (T *)(smem + SYN_OFF_TAB);                        // tab_entries (quarter + 1 rounded up to 32)
+    T *per = tab + tab_entries;                                // [2][SYN_MAX_STRIDE]
     const int tid = threadIdx.x;
-    for (int i = tid; i < n_tones; i += SYN_BLOCK) tones[i] = g_tones[i];
-    const int sr = 4 * quarter;
+    for (int i = tid; i <= quarter; i += SYN_BLOCK) tab[tab_pos(i)] = g_tab[i];
+    const int sr = 4 * quarter, half = 2 * quarter;
     const float inv_sr = 1.0f / (float)sr;
     typedef typename Vec4<T>::type V4;
+    auto sine = [&](int m) -> T {          // amp*sin(2*pi*m/sr), 0 <= m < sr
+        const bool neg = m >= half;
+        const int m2 = neg ? m - half : m;
+        const T v = tab[tab_pos(m2 > quarter ? half - m2 : m2)];
+        return neg ? (T)(-v) : v;
+    };
+    auto build = [&](T *dst, int f, int period) {   // one period of the f-Hz tone and its first three samples again
+        for (int i = tid; i < period + 3; i += SYN_BLOCK) {
+            const int ii = i >= period ? i - period : i;
+            dst[i] = sine(mod_sr((unsigned)f * (unsigned)ii, sr, inv_sr));
+        }
+    };
 
     const long long n_items = n_frames * parts;
     for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const long long f = item / parts;
         const int part = (int)(item - f * parts);
-        __syncthreads();  // descriptors ready / previous item's tables no longer read
+        __syncthreads();  // quarter-wave table ready / previous item's tables no longer read
         const int ns = n_segs[f];
         for (int i = tid; i <= ns; i += SYN_BLOCK) s_start[i] = seg_start[f * (long long)(seg_cap + 1) + i];
         for (int i = tid; i < ns; i += SYN_BLOCK) {
-            const int fq = seg_freq[f * (long long)seg_cap + i];
-            int lo = 0, hi = n_tones;            // first descriptor with freq >= fq
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (tones[mid].freq < fq) lo = mid + 1; else hi = mid;
+            const unsigned fq = (unsigned)seg_freq[f * (long long)seg_cap + i] % (unsigned)sr;
+            unsigned g = (unsigned)sr, r = fq;     // gcd(sr, fq) by Euclid; fq = 0 gives sr, a period of one sample
+            while (r) {
+                const unsigned t = g % r;
+                g = r;
+                r = t;
             }
+            const unsigned period = (unsigned)sr / g;
             s_freq[i] = (uint16_t)fq;
-            s_tone[i] = (lo < n_tones && tones[lo].freq == fq) ? (uint16_t)lo : (uint16_t)0xFFFF;
+            s_period[i] = period + 3 <= SYN_MAX_STRIDE ? (uint16_t)period : (uint16_t)0;
         }
         __syncthreads();
         const int total = s_start[ns];
@@ -289,43 +194,81 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
             }
             sg = lo;
         }
-        int cur = 0;
-        if (sg < ns && s_tone[sg] != 0xFFFF) {
-            const wn_tone t = tones[s_tone[sg]];
-            const V4 *src = (const V4 *)(g_per + t.offset);
-            V4 *d = (V4 *)s_per[0];
-            for (int i = tid; i < (t.stride >> 2); i += SYN_BLOCK) d[i] = src[i];
+        if ((long long)total < (long long)ns * (16 * SYN_BLOCK)) {
+            // Short segments (fewer than four steps of the workgroup each, as in the prototype
+            // scheme): going segment by segment would leave most lanes idle, so the threads
+            // walk the part as one run of vectors, each keeping its own current segment.
+            int lo = sg < ns ? s_start[sg] : total;
+            int hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
+            int fq = sg < ns ? s_freq[sg] : 0;
+            const int head = (4 - ((mis + p0) & 3)) & 3;        // samples before the first aligned vector
+            for (int p = p0 - ((4 - head) & 3) + 4 * tid; p < p1; p += 4 * SYN_BLOCK) {
+                const int q0 = p < p0 ? p0 : p;                 // the first vector may start before the part
+                const int q1 = p + 4 < p1 ? p + 4 : p1;
+                while (q0 >= hi) {
+                    ++sg;
+                    lo = hi;
+                    hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
+                    fq = sg < ns ? s_freq[sg] : 0;
+                }
+                if (q0 == p && q1 == p + 4 && (sg >= ns || p + 3 < hi)) {   // a whole vector inside one segment
+                    V4 o = {};
+                    if (sg < ns) {
+                        int m = mod_sr((unsigned)fq * (unsigned)(p - lo), sr, inv_sr);
+                        T e[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            e[k] = sine(m);
+                            m += fq;
+                            m = m >= sr ? m - sr : m;
+                        }
+                        o.x = e[0]; o.y = e[1]; o.z = e[2]; o.w = e[3];
+                    }
+                    *(V4 *)(out + p) = o;
+                } else {                                         // a boundary inside: sample by sample
+                    int sl = sg, ll = lo, hl = hi, fl = fq;
+                    for (int q = q0; q < q1; ++q) {
+                        while (q >= hl) {
+                            ++sl;
+                            ll = hl;
+                            hl = sl < ns ? s_start[sl + 1] : 0x7fffffff;
+                            fl = sl < ns ? s_freq[sl] : 0;
+                        }
+                        out[q] = sl < ns ? sine(mod_sr((unsigned)fl * (unsigned)(q - ll), sr, inv_sr)) : (T)0;
+                    }
+                }
+            }
+            continue;
         }
+        // a table pays when the segment is several periods long; otherwise straight from the
+        // quarter-wave table
+        auto table_period = [&](int g) -> int {
+            const int period = s_period[g];
+            return (period && 4 * (period + 3) <= s_start[g + 1] - s_start[g]) ? period : 0;
+        };
+        int cur = 0;
+        int period = sg < ns ? table_period(sg) : 0;
+        if (period) build(per, s_freq[sg], period);
         __syncthreads();
         while (sg < ns) {
             const int lo = s_start[sg], hi = s_start[sg + 1];
             if (lo >= p1) break;
             const int a = lo > p0 ? lo : p0, b = hi < p1 ? hi : p1;
-            const int ti = s_tone[sg];
             const int nx = sg + 1;
-            const int tn = (nx < ns && hi < p1) ? s_tone[nx] : 0xFFFF;
-            V4 pre0 = {}, pre1 = {};
-            int nv4 = 0;
-            if (tn != 0xFFFF) {                // next tone on its way while this one is written
-                const wn_tone t = tones[tn];
-                const V4 *src = (const V4 *)(g_per + t.offset);
-                nv4 = t.stride >> 2;
-                if (tid < nv4) pre0 = src[tid];
-                if (tid + SYN_BLOCK < nv4) pre1 = src[tid + SYN_BLOCK];
-            }
-            if (ti != 0xFFFF) {
-                const int period = tones[ti].period;
-                const T *tab = s_per[cur];
-                int va = a + ((4 - ((mis + a) & 3)) & 3);
-                va = va > b ? b : va;
-                const int vb = va + ((b - va) & ~3);
+            const int period_nx = (nx < ns && hi < p1) ? table_period(nx) : 0;
+            if (period_nx) build(per + (cur ^ 1) * SYN_MAX_STRIDE, s_freq[nx], period_nx);
+            int va = a + ((4 - ((mis + a) & 3)) & 3);    // first aligned vector of the segment
+            va = va > b ? b : va;
+            const int vb = va + ((b - va) & ~3);         // end of the last one
+            if (period) {
+                const T *tone = per + cur * SYN_MAX_STRIDE;
                 int v = va + 4 * tid;
                 if (v < vb) {
                     int j = (int)((unsigned)(v - lo) % (unsigned)period);
                     const int jstep = (4 * SYN_BLOCK) % period;
                     for (; v < vb; v += 4 * SYN_BLOCK) {
                         V4 o;
-                        o.x = tab[j]; o.y = tab[j + 1]; o.z = tab[j + 2]; o.w = tab[j + 3];
+                        o.x = tone[j]; o.y = tone[j + 1]; o.z = tone[j + 2]; o.w = tone[j + 3];
                         *(V4 *)(out + v) = o;
                         j += jstep;
                         j = j >= period ? j - period : j;
@@ -334,26 +277,32 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_period_kernel(
                 if (tid < 8) {                 // up to three samples before va and after vb
                     const int pos = tid < 4 ? a + tid : vb + (tid - 4);
                     const int lim = tid < 4 ? va : b;
-                    if (pos < lim) out[pos] = tab[(unsigned)(pos - lo) % (unsigned)period];
+                    if (pos < lim) out[pos] = tone[(unsigned)(pos - lo) % (unsigned)period];
                 }
-            } else {                           // a frequency without a table: sample by sample
+            } else {
                 const int fq = s_freq[sg];
-                const int half = 2 * quarter;
-                for (int pos = a + tid; pos < b; pos += SYN_BLOCK) {
-                    const int m = mod_sr((unsigned)fq * (unsigned)(pos - lo), sr, inv_sr);
-                    const bool neg = m >= half;
-                    const int m2 = neg ? m - half : m;
-                    const T t = g_tab[m2 > quarter ? half - m2 : m2];
-                    out[pos] = neg ? (T)(-t) : t;
+                for (int v = va + 4 * tid; v < vb; v += 4 * SYN_BLOCK) {
+                    int m = mod_sr((unsigned)fq * (unsigned)(v - lo), sr, inv_sr);
+                    T e[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        e[k] = sine(m);
+                        m += fq;
+                        m = m >= sr ? m - sr : m;
+                    }
+                    V4 o;
+                    o.x = e[0]; o.y = e[1]; o.z = e[2]; o.w = e[3];
+                    *(V4 *)(out + v) = o;
                 }
-            }
-            if (tn != 0xFFFF) {
-                V4 *d = (V4 *)s_per[cur ^ 1];
-                if (tid < nv4) d[tid] = pre0;
-                if (tid + SYN_BLOCK < nv4) d[tid + SYN_BLOCK] = pre1;
+                if (tid < 8) {
+                    const int pos = tid < 4 ? a + tid : vb + (tid - 4);
+                    const int lim = tid < 4 ? va : b;
+                    if (pos < lim) out[pos] = sine(mod_sr((unsigned)fq * (unsigned)(pos - lo), sr, inv_sr));
+                }
             }
             __syncthreads();  // next tone visible / everyone is done with this one
             cur ^= 1;
+            period = period_nx;
             sg = nx;
         }
         // past the frame: zero fill
@@ -430,18 +379,16 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     if (n == 0) return WN_OK;
     WN_REQUIRE_DEVICE(ctx);
     const size_t esz = fmt == WN_FMT_F32 ? 4 : 2;
-    const bool tabulated = ctx->n_tones > 0 && ctx->n_tones <= SYN_MAX_TONES;
     const size_t tab_entries = ((size_t)ctx->quarter + 1 + 31) & ~(size_t)31;
-    const size_t lds = tabulated ? 0 : (SYN_MAX_SEGS + 1) * 4 + SYN_MAX_SEGS * 2 + 8 + tab_entries * esz;
+    const size_t lds = SYN_OFF_TAB + (tab_entries + 2 * SYN_MAX_STRIDE) * esz;
     WN_REQUIRE(lds <= 150 * 1024, "sample_rate too large for the LDS sine table");
-    // one launch = as many workgroups as stay resident, each looping over (frame, part)
-    // items; parts of a frame balance the load when there are few frames
-    int per_cu = tabulated ? 2 : (int)((160 * 1024) / lds);
-    if (per_cu > 2048 / SYN_BLOCK) per_cu = 2048 / SYN_BLOCK;
+    // one launch = as many workgroups as stay resident, each looping over (frame, part) items
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("WN_SYNTH_PER_CU")) {
         const int v = atoi(e);
-        if (v >= 1 && v <= 2048 / SYN_BLOCK) per_cu = v;
+        if (v >= 1 && v <= 2048 / SYN_BLOCK && (size_t)v * lds <= 160 * 1024) per_cu = v;
     }
     const long long resident = (long long)ctx->num_cus * per_cu;
     // Large parts amortise the per-part set-up (segment table, first tone): 192 Ki samples
@@ -449,11 +396,8 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     // ones (down to 16 Ki) when there are few frames.  Measured on 122 GB of output: 5.7-6.1
     // TB/s for parts of 192 Ki..4 Mi samples and 1-3 workgroups per CU, 5.1 TB/s at 48 Ki.
     // WN_SYNTH_PART / WN_SYNTH_PER_CU override the choice for tuning.
-    long long part_want = 98304;
-    if (tabulated) {
-        part_want = (n * slot_len / (resident * 4) + 4095) & ~4095ll;
-        part_want = part_want < 16384 ? 16384 : (part_want > 196608 ? 196608 : part_want);
-    }
+    long long part_want = (n * slot_len / (resident * 4) + 4095) & ~4095ll;
+    part_want = part_want < 16384 ? 16384 : (part_want > 196608 ? 196608 : part_want);
     if (const char *e = getenv("WN_SYNTH_PART")) {
         const long long v = atoll(e);
         if (v >= 4096) part_want = v;
@@ -466,24 +410,9 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     const long long items = n * parts;
     const long long blocks = items < resident ? items : resident;
     hipStream_t st = (hipStream_t)stream;
-    if (tabulated) {
-        if (fmt == WN_FMT_F32)
-            hipLaunchKernelGGL(synth_period_kernel<float>, dim3((unsigned)blocks), dim3(SYN_BLOCK), 0, st, d_seg_start,
-                               d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,
-                               (const long long *)d_dst_off, (const long long *)d_fill_to, (float *)d_audio,
-                               (long long)audio_len, (const float *)ctx->d_sin_f32, ctx->quarter,
-                               (const wn_tone *)ctx->d_tones, ctx->n_tones, (const float *)ctx->d_per_f32);
-        else
-            hipLaunchKernelGGL(synth_period_kernel<int16_t>, dim3((unsigned)blocks), dim3(SYN_BLOCK), 0, st,
-                               d_seg_start, d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts,
-                               (int)part_len, (const long long *)d_dst_off, (const long long *)d_fill_to,
-                               (int16_t *)d_audio, (long long)audio_len, (const int16_t *)ctx->d_sin_i16, ctx->quarter,
-                               (const wn_tone *)ctx->d_tones, ctx->n_tones, (const int16_t *)ctx->d_per_i16);
-        return wn_launch_check("synth_period_kernel");
-    }
+    static size_t attr_lds[2][WN_MAX_DEVICES];   // largest dynamic LDS size allowed so far, per format and device
+    size_t &attr = attr_lds[fmt == WN_FMT_F32 ? 0 : 1][ctx->device];
     if (fmt == WN_FMT_F32) {
-        static size_t attr_lds[WN_MAX_DEVICES];
-        size_t &attr = attr_lds[ctx->device];
         if (lds > attr) {
             WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<float>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -492,10 +421,8 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
         hipLaunchKernelGGL(synth_kernel<float>, dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,
                            d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,
                            (const long long *)d_dst_off, (const long long *)d_fill_to, (float *)d_audio,
-                           (long long)audio_len, (const float *)ctx->d_sin_f32, ctx->quarter);
+                           (long long)audio_len, (const float *)ctx->d_sin_f32, ctx->quarter, (int)tab_entries);
     } else {
-        static size_t attr_lds[WN_MAX_DEVICES];
-        size_t &attr = attr_lds[ctx->device];
         if (lds > attr) {
             WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<int16_t>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -504,7 +431,7 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
         hipLaunchKernelGGL(synth_kernel<int16_t>, dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,
                            d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,
                            (const long long *)d_dst_off, (const long long *)d_fill_to, (int16_t *)d_audio,
-                           (long long)audio_len, (const int16_t *)ctx->d_sin_i16, ctx->quarter);
+                           (long long)audio_len, (const int16_t *)ctx->d_sin_i16, ctx->quarter, (int)tab_entries);
     }
     return wn_launch_check("synth_kernel");
 }
