@@ -209,6 +209,38 @@ def test_synth_unaligned_destination_and_no_fill(mb):
     assert np.max(np.abs(a[3:n + 3] - ref)) <= 6e-8 and np.max(np.abs(a[n + 10:2 * n + 10] - ref)) <= 6e-8
 
 
+@pytest.mark.parametrize("scheme", ["B", "A"])
+@pytest.mark.parametrize("part", [4096, 20000])
+def test_synth_small_parts_and_misaligned_slots(mb, ma, scheme, part, monkeypatch):
+    """Many parts per frame (part boundaries inside tones) and slots that start at every
+    alignment modulo 4 samples, with and without zero fill after the frame, for the live scheme
+    (segment by segment from period tables) and the prototype (short segments, one run of
+    vectors): every sample equals the oracle's, nothing outside the slots is touched."""
+    monkeypatch.setenv("WN_SYNTH_PART", str(part))
+    m, sch = (mb, SB) if scheme == "B" else (ma, SA)
+    rng = np.random.default_rng(part)
+    if scheme == "B":
+        msgs = [mo.build_frame(1, MAC_O, MAC_D, 3, bytes(rng.integers(0, 256, k).tolist())) for k in (0, 3, 1, 2)]
+    else:
+        msgs = [bytes(rng.integers(0, 128, k).tolist()) for k in (5, 17, 1, 9)]
+    refs = [mo.emit_frame(f, sch).astype(np.float32) for f in msgs]
+    buf, lens = rows_from(msgs, 32)
+    lay = m.layout(dev(buf), dev(lens))
+    slot = M.pad4(max(len(r) for r in refs) + 40)
+    offs = [k * (slot + 8) + k for k in range(4)]                  # alignments 0, 1, 2, 3
+    audio = torch.full((4 * (slot + 8) + 16,), 7.0, dtype=torch.float32, device="cuda")
+    fill = torch.tensor([len(refs[0]), len(refs[1]) + 13, slot, slot - 2], dtype=torch.int64, device="cuda")
+    m.synth(lay, torch.tensor(offs, dtype=torch.int64, device="cuda"), audio, slot, fill)
+    a = audio.cpu().numpy()
+    written = np.zeros(len(a), dtype=bool)
+    for off, ref, end in zip(offs, refs, fill.cpu().tolist()):
+        end = max(end, len(ref))
+        assert np.max(np.abs(a[off:off + len(ref)] - ref)) <= 6e-8
+        assert not a[off + len(ref):off + end].any()
+        written[off:off + end] = True
+    assert np.all(a[~written] == 7.0)
+
+
 def test_synth_wav_int16(mb, ma, golden):
     g = golden["wav_b"]
     f = bytes.fromhex(g["frame"])
