@@ -34,7 +34,9 @@ __device__ __forceinline__ uint32_t crc_lds_row(const uint32_t *tab, const uint8
 }
 
 // MODE 0: d_out32[row] = crc32(row[0..len)).  MODE 1: parse + validate into wn_frame_rec.
-template <int MODE>
+// PPR > 0: the stride is 16*PPR bytes and the loads of a tile are all issued before the first
+// LDS write (one trip to HBM per tile instead of one per piece); PPR = 0: any stride.
+template <int MODE, int PPR>
 __global__ __launch_bounds__(CRC_BLOCK) void crc_rows_kernel(const uint8_t *__restrict__ rows,
                                                              const int32_t *__restrict__ lens, int stride,
                                                              long long n, const uint32_t *__restrict__ g_tab,
@@ -61,13 +63,29 @@ __global__ __launch_bounds__(CRC_BLOCK) void crc_rows_kernel(const uint8_t *__re
         }
         // stage: piece p = (row p/ppr, 16-byte column p%ppr)
         const uint4 *src = (const uint4 *)(rows + row0 * (long long)stride);
-        for (int p = lane; p < 64 * ppr; p += 64) {
-            const int r = p / ppr, c = p - r * ppr;
-            const int rl = __shfl(my_len, r);
-            if (c * 16 < rl) {
-                const uint4 v = src[p];
+        if constexpr (PPR > 0) {
+            uint4 v[PPR];
+#pragma unroll
+            for (int i = 0; i < PPR; ++i) {
+                const int p = lane + 64 * i, r = p / PPR, c = p % PPR;
+                v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (c * 16 < __shfl(my_len, r)) v[i] = src[p];
+            }
+#pragma unroll
+            for (int i = 0; i < PPR; ++i) {
+                const int p = lane + 64 * i, r = p / PPR, c = p % PPR;
                 uint32_t *dst = (uint32_t *)(tile + r * lrow + c * 16);
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                dst[0] = v[i].x; dst[1] = v[i].y; dst[2] = v[i].z; dst[3] = v[i].w;
+            }
+        } else {
+            for (int p = lane; p < 64 * ppr; p += 64) {
+                const int r = p / ppr, c = p - r * ppr;
+                const int rl = __shfl(my_len, r);
+                if (c * 16 < rl) {
+                    const uint4 v = src[p];
+                    uint32_t *dst = (uint32_t *)(tile + r * lrow + c * 16);
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                }
             }
         }
         // a wave only reads what it wrote itself; LDS ops of one wave complete in order
@@ -204,12 +222,16 @@ static int launch_rows(wn_ctx *ctx, const uint8_t *rows, const int32_t *lens, in
         if (blocks > cap) blocks = cap;
         static size_t attr_lds[WN_MAX_DEVICES];   // largest dynamic LDS size allowed so far, per device
         if (lds > 48 * 1024 && lds > attr_lds[ctx->device]) {
-            WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_rows_kernel<MODE>,
+            WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_rows_kernel<MODE, 0>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_lds[ctx->device] = lds;
         }
-        hipLaunchKernelGGL(crc_rows_kernel<MODE>, dim3((unsigned)blocks), dim3(CRC_BLOCK), lds, st, rows, lens,
-                           (int)stride, (long long)n, ctx->d_crc_tab, out32, out_rec);
+        if (stride == 128)
+            hipLaunchKernelGGL((crc_rows_kernel<MODE, 8>), dim3((unsigned)blocks), dim3(CRC_BLOCK), lds, st, rows, lens,
+                               (int)stride, (long long)n, ctx->d_crc_tab, out32, out_rec);
+        else
+            hipLaunchKernelGGL((crc_rows_kernel<MODE, 0>), dim3((unsigned)blocks), dim3(CRC_BLOCK), lds, st, rows, lens,
+                               (int)stride, (long long)n, ctx->d_crc_tab, out32, out_rec);
         return wn_launch_check("crc_rows_kernel");
     }
     long long blocks = (n + CRC_BLOCK - 1) / CRC_BLOCK;
