@@ -674,8 +674,12 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     // in out_bin[0..8]
     const bool prof = getenv("WN_DETECT_PROFILE") && atoi(getenv("WN_DETECT_PROFILE")) != 0;
     const long long total = n_streams * n_windows;
+    // one workgroup per CU for the long window (its four window buffers fill the LDS); short
+    // windows leave room for two, and a second wave per SIMD runs its vector-ALU work under
+    // the first one's matrix instructions
+    constexpr int PER_CU = (2 * P::LDS <= 160 * 1024 && 2 * (P::TA * 16 + 160) <= 512) ? 2 : 1;
     long long blocks = (total + 3) / 4;
-    if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+    if (blocks > (long long)ctx->num_cus * PER_CU) blocks = (long long)ctx->num_cus * PER_CU;
     // squared magnitudes are compared, through keys that drop up to 2^-11 of the value
     const double k = (1.0 - ctx->tie_band) * (1.0 - ctx->tie_band) / (1.0 + 1.0 / 2048.0) * (1.0 - 1e-6);
     if (prof)
