@@ -513,6 +513,31 @@ def test_sync_scan_energies_and_sound_verdicts(mb, golden):
         assert vd[8] == 0
 
 
+def test_capture_cut_into_window_ranges(mb, golden):
+    """One capture held in pieces (how a long capture is spread over several GPUs): detection
+    of each window range on its own copy gives the same class words as detection of the whole,
+    and the listen loop over the collected words returns the same frames."""
+    from wavenet_amd import sharding as SH
+    s = golden["listen_b"][4]
+    x32 = capture_of(s).astype(np.float32)
+    nwin = len(x32) // 7055
+    whole = np.zeros(M.pad4(nwin * 7055), dtype=np.float32)
+    whole[:nwin * 7055] = x32[:nwin * 7055]
+    timeout, calls = 60.0, len(s["frames"]) + 1
+    ref = mb.decode_streams(dev(whole), 1, len(whole), nwin, timeout, max_calls=calls)
+    pieces = []
+    for r in range(3):
+        lo, hi = SH.shard_range(nwin, r, 3)
+        local = np.zeros(M.pad4((hi - lo) * 7055), dtype=np.float32)
+        local[:(hi - lo) * 7055] = whole[lo * 7055:hi * 7055]
+        pieces.append(mb.detect(dev(local), 1, len(local), hi - lo)[0].view(-1))
+    assert torch.equal(torch.cat(pieces), ref["cls"].view(-1))
+    got = SH.decode_capture_sharded(mb, dev(whole), nwin, timeout, calls)       # one rank: the whole range
+    for k in ("cls", "bytes", "lens", "start", "end", "reason", "n_calls"):
+        assert torch.equal(got[k].view(-1), ref[k].view(-1)), k
+    assert int(got["n_calls"][0]) >= len(s["frames"])
+
+
 # ------------------------------------------------------------------------------- round trip at scale
 def test_roundtrip_many_streams_max_payload(mb):
     """Configuration 2 in small: independent streams, one 107-byte frame each, encode on the

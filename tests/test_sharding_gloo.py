@@ -61,8 +61,33 @@ def test_gather_records_two_ranks(n_total):
     procs = [ctx.Process(target=_worker, args=(r, 2, n_total, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    assert results == [True, True]
+    assert [q.get(timeout=10) for _ in procs] == [True, True]
+
+
+def _worker_windows(rank, world, n_windows, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    whole = ((torch.arange(n_windows, dtype=torch.int64) * 2654435761) % 1021).to(torch.int16)
+    lo, hi = SH.shard_range(n_windows, rank, world)
+    got = SH.gather_window_classes(whole[lo:hi].clone(), n_windows)
+    q.put(bool(torch.equal(got, whole)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_windows", [22503, 7])
+def test_gather_window_classes_two_ranks(n_windows):
+    """One capture cut into two window ranges: both ranks end with the whole class sequence."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + n_windows % 7
+    procs = [ctx.Process(target=_worker_windows, args=(r, 2, n_windows, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [q.get(timeout=10) for _ in procs] == [True, True]

@@ -6,6 +6,11 @@ encode/decode path on them with no data-path collective.  The only exchange is t
 of fixed-size decoded-frame records on one rank (RCCL over xGMI when the tensors live on
 GPUs, gloo on CPU tensors in the tests): 128 frame bytes + 8 bytes of parse record +
 4 bytes of length per stream, about 14 MB for 100 000 streams, latency-bound.
+
+One long capture shards by window ranges instead: windows are independent for detection and
+for the ping search, only the receive state machine is sequential, and it runs over class
+words (2 bytes per window: 45 KB for an hour of audio), which every rank collects with one
+all-gather.
 """
 from __future__ import annotations
 
@@ -62,3 +67,45 @@ def gather_records(packed: torch.Tensor, n_total: int, dst: int = 0):
         lo, hi = shard_range(n_total, r, world)
         parts.append(bufs[r][:hi - lo])
     return torch.cat(parts, dim=0)
+
+
+def gather_window_classes(cls_local: torch.Tensor, n_windows: int) -> torch.Tensor:
+    """One capture cut into contiguous window ranges (shard_range over its n_windows): every
+    rank passes the class words of its own range, [hi-lo] int16, and gets the whole sequence
+    [n_windows] back, ready for the state machine.  Ranges may differ by one window, so each
+    rank pads to the largest."""
+    assert cls_local.dtype == torch.int16 and cls_local.dim() == 1
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert cls_local.numel() == n_windows
+        return cls_local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(n_windows, rank, world)
+    assert cls_local.numel() == hi - lo
+    biggest = -(-n_windows // world)
+    pad = torch.zeros(biggest, dtype=torch.int16, device=cls_local.device)
+    pad[:hi - lo] = cls_local
+    wire = pad.view(torch.uint8)          # bytes on the wire: every backend moves uint8
+    bufs = [torch.empty_like(wire) for _ in range(world)]
+    dist.all_gather(bufs, wire)
+    parts = []
+    for r in range(world):
+        rlo, rhi = shard_range(n_windows, r, world)
+        parts.append(bufs[r].view(torch.int16)[:rhi - rlo])
+    return torch.cat(parts)
+
+
+def decode_capture_sharded(modem, audio_local: torch.Tensor, n_windows: int, timeout: float, max_calls: int,
+                           frame_cap: int = 128):
+    """The listen loop over one long capture held in pieces: rank r's `audio_local` starts at
+    the first sample of its window range (shard_range(n_windows, r, world) windows of
+    win_n samples, padded to a multiple of 4).  Detection runs on the local range, the class
+    words are all-gathered, and every rank runs the state machine and the frame parse over the
+    whole sequence (they are tiny), so all ranks return the same frames."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_range(n_windows, rank, world)
+    cls_local, _, _ = modem.detect(audio_local, 1, audio_local.numel(), hi - lo)
+    cls = gather_window_classes(cls_local.view(-1), n_windows).view(1, n_windows).contiguous()
+    by, lens, start, end, reason, n_calls = modem.slice(cls, modem.timeout_windows(timeout), max_calls, frame_cap)
+    rec = modem.parse_frames(by.view(max_calls, frame_cap), lens.view(-1))
+    return dict(cls=cls, bytes=by, lens=lens, start=start, end=end, reason=reason, n_calls=n_calls, rec=rec)
