@@ -1,77 +1,96 @@
 """`DispositivoWaveNet`: the layer-1 device the upper layers talk to (reference
 DispositivoWaveNET/dispositivo_wavenet/dispositivo_wavenet.py:17-52; its only in-repo
-caller is SoundProtocol, WaveNetCore/wavenetcore/WaveNetProtocols.py:295-329).
+caller is SoundProtocol, WaveNetCore/wavenetcore/WaveNetProtocols.py:295-329), and the
+command line of the same file (:54-98).
 
-Same constructor, same two methods, same two exception messages.  The sound card is the
-synthetic channel installed with `c1_shared.usar_canal`; with no peer on it both methods
-fail the way the reference does on a machine nobody answers.
+Same constructor, same two methods, same two exception messages, same options and modes.
+The sound card is the synthetic channel installed with `c1_shared.usar_canal`; with no peer
+on it both methods fail the way the reference does on a machine nobody answers.
 """
 import argparse
 import os
 
-from .c1_communication import *  # noqa: F401,F403
-from .c1_communication import (TIME_TO_SAY_128_BYTES, cargar_wavs_en_canal, enviar_archivo_por_sonido,
-                               enviar_string_por_sonido, escuchar_archivo, escuchar_string,
-                               escuchar_y_retornar_trama, guardar_archivo_en_tramas_wav)
+from . import c1_communication as _l1
+from .c1_communication import *  # noqa: F401,F403  (the reference module re-exports layer 1 the same way)
 
 
 class DispositivoWaveNet:
+    """One machine's layer-1 endpoint: its own MAC and, for sending, its peer's."""
+
+    #: texts the upper layers see when a transfer fails (dispositivo_wavenet.py:40, 51)
+    ERROR_ENVIO = "Failed to send string through layer 1"
+    ERROR_ESCUCHA = "Failed to get string from layer 1"
+
     def __init__(self, mac_origen, mac_destino=None):
-        self.mac_origen = mac_origen
-        self.mac_destino = mac_destino
+        self.mac_origen, self.mac_destino = mac_origen, mac_destino
 
     def send(self, string, timeout=None):
-        if not enviar_string_por_sonido(string, self.mac_origen, self.mac_destino, timeout=timeout):
-            raise Exception("Failed to send string through layer 1")
+        entregado = _l1.enviar_string_por_sonido(string, self.mac_origen, self.mac_destino, timeout=timeout)
+        if not entregado:
+            raise Exception(self.ERROR_ENVIO)
 
     def listen(self, timeout=None, init_timeout=None):
-        ret = escuchar_string(self.mac_origen, timeout=timeout, init_timeout=init_timeout)
-        if ret == False:  # noqa: E712  (the reference tests equality, so an empty string fails too)
-            raise Exception("Failed to get string from layer 1")
-        return ret
+        texto = _l1.escuchar_string(self.mac_origen, timeout=timeout, init_timeout=init_timeout)
+        if texto == False:  # noqa: E712  (the reference's own test: False fails, an empty text does not)
+            raise Exception(self.ERROR_ESCUCHA)
+        return texto
+
+
+def _modo_wav(a):
+    _l1.guardar_archivo_en_tramas_wav(a.archivo, a.mac_origen, a.mac_destino)
+
+
+def _modo_oir_trama(a):
+    try:
+        _l1.escuchar_y_retornar_trama(_l1.TIME_TO_SAY_128_BYTES).imprimir()
+    except Exception:
+        print("No se escuho ninguna trama en el tiempo establecido.")
+
+
+def _avisar(exito, texto):
+    if not exito:
+        print(texto)
+
+
+# mode -> (needs the file to exist, action); the texts are the reference's (dispositivo_wavenet.py:66-92)
+_MODOS = {
+    "1": (True, _modo_wav),
+    "2": (False, _modo_oir_trama),
+    "3": (True, lambda a: _avisar(_l1.enviar_archivo_por_sonido(a.archivo, a.mac_origen, a.mac_destino),
+                                  "No se envio el archivo correctamente")),
+    "4": (False, lambda a: _avisar(_l1.escuchar_archivo(a.mac_origen), "No se escucho el archivo correctamente")),
+    "5": (False, lambda a: _avisar(_l1.enviar_string_por_sonido(a.archivo, a.mac_origen, a.mac_destino),
+                                   "No se envio el archivo correctamente")),
+    "6": (False, lambda a: _avisar(_l1.escuchar_string(a.mac_origen), "No se escucho el archivo correctamente")),
+}
+
+
+def _argumentos(argv):
+    p = argparse.ArgumentParser(description="Capa 1 de WaveNet sobre el canal sintetico")
+    for corta, larga, obligatoria, ayuda in (
+            ("-a", "--archivo", True, "archivo a enviar, o texto en los modos 5 y 6"),
+            ("-b", "--mac_origen", True, "MAC de esta maquina, aa:bb:cc:dd:ee:ff"),
+            ("-c", "--mac_destino", False, "MAC de la otra maquina"),
+            ("-d", "--modo", True, "1 WAV por trama, 2 oir una trama, 3/4 enviar/oir archivo, 5/6 enviar/oir texto")):
+        p.add_argument(corta, larga, required=obligatoria, help=ayuda)
+    # no counterpart in the reference, whose capture is the sound card
+    p.add_argument("-w", "--captura", action="append", default=[],
+                   help="WAV que se carga en el canal antes de escuchar (repetible)")
+    return p.parse_args(argv)
 
 
 def main(argv=None):
-    """The reference's command line (dispositivo_wavenet.py:54-98): same options and modes.
-    The listening modes hear the current synthetic channel; `-w` (no counterpart in the
-    reference, whose capture is the sound card) loads WAV files into it first."""
-    parser = argparse.ArgumentParser(description="Parser de archivo y direcciones MAC")
-    parser.add_argument('-a', '--archivo', required=True, help="Ruta al archivo (ej: archivo.txt)")
-    parser.add_argument('-b', '--mac_origen', required=True, help="MAC Address de origen (ej: aa:bb:cc:dd:ee:ff)")
-    parser.add_argument('-c', '--mac_destino', required=False, help="MAC Address de destino (ej: 11:22:33:44:55:66)")
-    parser.add_argument('-d', '--modo', required=True)
-    parser.add_argument('-w', '--captura', action='append', default=[],
-                        help="archivo WAV que se carga como captura antes de escuchar (repetible)")
-    args = parser.parse_args(argv)
-    ruta = args.archivo
-
-    if (args.modo == "1" or args.modo == "3") and not os.path.exists(ruta):
-        print(f"El archivo {ruta} no existe.")
+    """The listening modes hear the current synthetic channel; `-w` loads WAV files into it first."""
+    a = _argumentos(argv)
+    necesita_archivo, accion = _MODOS.get(a.modo, (False, None))
+    if necesita_archivo and not os.path.exists(a.archivo):
+        print(f"El archivo {a.archivo} no existe.")
         return
-    if args.captura:
-        cargar_wavs_en_canal(args.captura)
-
-    if args.modo == "1":
-        guardar_archivo_en_tramas_wav(ruta, args.mac_origen, args.mac_destino)
-    elif args.modo == "2":
-        try:
-            tramita = escuchar_y_retornar_trama(TIME_TO_SAY_128_BYTES)
-            tramita.imprimir()
-        except Exception:
-            print("No se escuho ninguna trama en el tiempo establecido.")
-    elif args.modo == "3":
-        if not enviar_archivo_por_sonido(ruta, args.mac_origen, args.mac_destino):
-            print("No se envio el archivo correctamente")
-    elif args.modo == "4":
-        if not escuchar_archivo(args.mac_origen):
-            print("No se escucho el archivo correctamente")
-    elif args.modo == "5":
-        if not enviar_string_por_sonido(ruta, args.mac_origen, args.mac_destino):
-            print("No se envio el archivo correctamente")
-    elif args.modo == "6":
-        if not escuchar_string(args.mac_origen):
-            print("No se escucho el archivo correctamente")
+    if a.captura:
+        _l1.cargar_wavs_en_canal(a.captura)
+    if accion is not None:          # an unknown mode does nothing, as in the reference
+        accion(a)
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     main()
