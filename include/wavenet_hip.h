@@ -158,7 +158,9 @@ int wn_channel_awgn(wn_ctx *ctx, float *d_audio, int64_t n, float sigma, uint64_
  * d_audio[s*stream_stride + first_sample + w*win_n .. +win_n), all s < n_streams,
  * w < n_windows.  Outputs are [n_streams][n_windows]: class word, |X| of the dominant
  * bin, and its index (first maximum over bins [0, win_n/2), as np.argmax).
- * d_audio must be 16-byte aligned and audio_len a multiple of 4. */
+ * d_audio must be 16-byte aligned and audio_len a multiple of 4.  Samples must be finite; any
+ * finite amplitude gives the float64 decision (windows too quiet or too loud for float32
+ * energies are re-evaluated in float64, all-zero windows give bin 0). */
 int wn_detect_windows(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
                       int64_t stream_stride, int64_t first_sample, int64_t n_windows,
                       uint16_t *d_cls, float *d_peak_mag, int32_t *d_peak_bin, void *stream);
