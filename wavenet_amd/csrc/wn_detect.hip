@@ -267,6 +267,19 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     }
     __syncthreads();
 
+    // bins of this lane's outputs (tile, register, column tile, plus/minus side), kept in
+    // registers for the whole launch
+    unsigned tag[TA][4][C2T][2];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < C2T; ++c) {
+                tag[t][r][c][0] = ep[(((t * 4 + r) * 64 + lane) << 3) + 2 * c];
+                tag[t][r][c][1] = ep[(((t * 4 + r) * 64 + lane) << 3) + 2 * c + 1];
+            }
+
     // ---- window staging by LDS-DMA
     auto fetch = [&](long long s, long long wi) {
         const long long g0 = s * stream_stride + first_sample + wi * (long long)N;
@@ -421,15 +434,6 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         best.mx = 0u;
         static_for<TA>([&](auto TT) {
             constexpr int tt = decltype(TT)::value;
-            uint4 epa[4];
-            uint2 epb[4];
-            static_for<4>([&](auto R) {   // bins of this tile's outputs, read under its MFMAs
-                constexpr int r = decltype(R)::value;
-                const uint32_t *e = ep + (((tt * 4 + r) * 64 + lane) << 3);
-                epa[r] = *(const uint4 *)e;
-                if constexpr (C2T > 2) epb[r] = *(const uint2 *)(e + 4);
-            });
-            __builtin_amdgcn_sched_barrier(0);
             floatx4 acc[4][C2T];   // the sums A, B, C, E
             static_for<KS2>([&](auto S) {
                 constexpr int s = decltype(S)::value, tau = s >> 2, r = s & 3;
@@ -466,8 +470,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     static_for<2>([&](auto EL) {
                         constexpr int r = 2 * hf + decltype(EL)::value;
                         float mp = mp2[decltype(EL)::value], mm = mm2[decltype(EL)::value];
-                        const unsigned tp = c == 0 ? epa[r].x : (c == 1 ? epa[r].z : (c == 2 ? epb[r].x : 0u));
-                        const unsigned tm = c == 0 ? epa[r].y : (c == 1 ? epa[r].w : (c == 2 ? epb[r].y : 0u));
+                        const unsigned tp = tag[tt][r][c][0], tm = tag[tt][r][c][1];
                         // outputs that must not compete although their value is not zero: known positions
                         constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
                         if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
