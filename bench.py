@@ -8,24 +8,42 @@ window, run the receive state machine and parse/validate the frames, all on the 
 With N > 1 every rank does the same amount of work on its own block of streams (weak
 scaling) and the decoded-frame records are gathered on rank 0 inside the timed region.
 
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment
+starts N rank processes itself (fresh children, started before this process has touched
+the GPU), one per device, and passes rank 0's line through.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` every process is
+already a rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+`--backend gloo --share-devices` runs the same multi-rank branch with several ranks on one
+device and the record gather over gloo (a rehearsal of the code path, not a measurement).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from wavenet_amd import modem as M          # noqa: E402
-from wavenet_amd import sharding as SH      # noqa: E402
+# torch, the modem and the sharding helpers are imported by the rank code only: the launching
+# parent must stay clear of the GPU runtime
+np = torch = dist = M = SH = None
+
+
+def _imports():
+    global np, torch, dist, M, SH
+    import numpy
+    import torch as _torch
+    import torch.distributed as _dist
+
+    from wavenet_amd import modem, sharding
+    np, torch, dist, M, SH = numpy, _torch, _dist, modem, sharding
+
 
 PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X dense f32 matrix peak
 WIN = 7055
@@ -88,29 +106,91 @@ def cpu_baseline_all_cores(n_streams):
     return audio_s / max(dt for _, dt in res), cores, wall
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = devices of this node to use")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=10000, help="streams per GPU")
     ap.add_argument("--cpu-streams", type=int, default=200, help="streams of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--sub-batches", type=int, default=0, help="split the streams of a step (0 = only if memory requires)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend of the record gather (nccl = RCCL; gloo stages through host memory)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="ranks may share a device (rank r uses device r mod device count): rehearsal of the "
+                         "multi-rank branch on a box with fewer devices than ranks; needs --backend gloo")
+    ap.add_argument("--rank-info", action="store_true",
+                    help="each rank prints its rank environment as one JSON line and exits (no GPU work)")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args):
+    """Parent of a self-launched multi-rank run: starts args.gpus children of this same script,
+    one rank each, and returns the first non-zero exit code (0 if all succeed).  The parent
+    makes no GPU call before or after (it has not even imported torch), so every rank is a
+    fresh process that initialises the GPU itself; nothing is re-executed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rank_info:
+        print(json.dumps({"rank": rank, "local_rank": local, "world": world, "pid": os.getpid(),
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        return
+    _imports()
+    launcher = "single process" if world == 1 else (
+        "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "bench.py --gpus")
     all_cores = None
     if args.cpu_streams > 0 and world == 1:
         all_cores = cpu_baseline_all_cores(max(1, args.cpu_streams // 2))
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py: no GPU visible; the modem runs as HIP kernels only")
+    if local >= n_dev:
+        if not args.share_devices:
+            raise SystemExit("bench.py: rank %d needs device %d but this node shows %d device(s) "
+                             "(--share-devices --backend gloo rehearses the multi-rank path on fewer)" % (rank, local, n_dev))
+        local %= n_dev
+    if args.share_devices and world > n_dev and args.backend != "gloo":
+        raise SystemExit("bench.py: ranks sharing a device cannot form an RCCL communicator; use --backend gloo")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
         # communicator set-up is not part of a step: run the collectives the steps use once,
         # on empty-sized data, before anything is timed (also when --warmup is 0)
-        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=device), op=dist.ReduceOp.MAX)
+        SH.all_reduce_max(0.0, device)
         SH.gather_records(torch.zeros((1, SH.RECORD_BYTES), dtype=torch.uint8, device=device), world, dst=0)
         dist.barrier()
 
@@ -177,9 +257,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = SH.all_reduce_max(elapsed, device)
 
     # correctness of what was timed: every stream's frame came back bit-exact and valid
     for frames, lens, by, ln, rec, end in outs:
@@ -187,9 +265,20 @@ def main():
         assert torch.equal(by[:, :126], frames[:, :126])
         r = rec.cpu().numpy().view(M.REC_DTYPE).reshape(-1)
         assert (r["status"] == 0).all() and (r["crc_ok"] == 1).all()
+    gathered_ok = None
     if rank == 0 and world > 1:
+        # the gathered records are every rank's frames in stream order: rank 0 rebuilds the frames
+        # of all S * world streams from their indices (inputs are a function of the index) and compares
         assert gathered.shape == (S * world, SH.RECORD_BYTES)
-        assert torch.equal(gathered[:S, :126], torch.cat([o[0] for o in outs])[:, :126])
+        g_bytes, g_lens, g_rec = SH.unpack_records(gathered)
+        assert bool((g_lens == 126).all())
+        for r in range(world):
+            f_r, p_r = make_inputs(S, r * S, device)
+            want, _ = m.build_frames(f_r, p_r, 128)
+            assert torch.equal(g_bytes[r * S:(r + 1) * S, :126], want[:, :126]), "records of rank %d" % r
+        gr = g_rec.contiguous().cpu().numpy().view(M.REC_DTYPE).reshape(-1)
+        assert (gr["status"] == 0).all() and (gr["crc_ok"] == 1).all() and (gr["length"] == 107).all()
+        gathered_ok = True
 
     if rank == 0:
         audio_s_per_step = world * S * nwin * WIN / 44100.0
@@ -220,6 +309,12 @@ def main():
                        "streams_per_gpu": S, "sub_batches": nb, "stream_stride_samples": stride,
                        "parallelism": "streams sharded by contiguous index blocks, gather of 140-B records"},
             "frames_per_s": world * S * args.steps / elapsed,
+            "launcher": launcher, "devices_visible": n_dev,
+            "gather": None if world == 1 else {
+                "backend": "RCCL all-gather of %d-byte records on device tensors" % SH.RECORD_BYTES
+                if args.backend == "nccl" else "gloo all-gather, records staged through host memory",
+                "records": S * world, "verified_in_stream_order": gathered_ok,
+                "ranks_share_devices": bool(world > n_dev)},
             "roofline": {"bound": "mfma", "kernel": "detect_kernel<83,85> (+ float64 re-evaluation pass)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,

@@ -46,16 +46,35 @@ def unpack_records(packed: torch.Tensor):
     return packed[:, :128], lens, packed[:, 128:136]
 
 
+def _wire_device(t: torch.Tensor) -> torch.device:
+    """Where a tensor has to live for the collective: RCCL moves device memory; gloo is used
+    with host memory (device tensors are staged through it)."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return t.device
+
+
+def all_reduce_max(value: float, device: torch.device) -> float:
+    """Largest `value` over the ranks (the benchmark's max-over-ranks step time)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = t.to(_wire_device(t))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def gather_records(packed: torch.Tensor, n_total: int, dst: int = 0):
     """Gathers every rank's packed records on rank `dst` in stream order.  Returns the
-    [n_total,140] tensor there and None elsewhere.  Shards may differ by one stream, so
-    each rank pads to the largest shard and rank dst trims."""
+    [n_total,140] tensor there (on the device of `packed`) and None elsewhere.  Shards may
+    differ by one stream, so each rank pads to the largest shard and rank dst trims."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return packed
     world, rank = dist.get_world_size(), dist.get_rank()
     biggest = -(-n_total // world)
-    pad = torch.zeros((biggest, RECORD_BYTES), dtype=torch.uint8, device=packed.device)
-    pad[:packed.shape[0]] = packed
+    wire = _wire_device(packed)
+    pad = torch.zeros((biggest, RECORD_BYTES), dtype=torch.uint8, device=wire)
+    pad[:packed.shape[0]] = packed.to(wire)
     # an all-gather rather than a gather: the same bytes on the wire for rank dst, a ring
     # collective every backend implements natively, and about 1.4 MB per rank per 10 000 streams
     bufs = [torch.empty_like(pad) for _ in range(world)]
@@ -66,7 +85,7 @@ def gather_records(packed: torch.Tensor, n_total: int, dst: int = 0):
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)
         parts.append(bufs[r][:hi - lo])
-    return torch.cat(parts, dim=0)
+    return torch.cat(parts, dim=0).to(packed.device)
 
 
 def gather_window_classes(cls_local: torch.Tensor, n_windows: int) -> torch.Tensor:
@@ -82,8 +101,9 @@ def gather_window_classes(cls_local: torch.Tensor, n_windows: int) -> torch.Tens
     lo, hi = shard_range(n_windows, rank, world)
     assert cls_local.numel() == hi - lo
     biggest = -(-n_windows // world)
-    pad = torch.zeros(biggest, dtype=torch.int16, device=cls_local.device)
-    pad[:hi - lo] = cls_local
+    dev = _wire_device(cls_local)
+    pad = torch.zeros(biggest, dtype=torch.int16, device=dev)
+    pad[:hi - lo] = cls_local.to(dev)
     wire = pad.view(torch.uint8)          # bytes on the wire: every backend moves uint8
     bufs = [torch.empty_like(wire) for _ in range(world)]
     dist.all_gather(bufs, wire)
@@ -91,7 +111,7 @@ def gather_window_classes(cls_local: torch.Tensor, n_windows: int) -> torch.Tens
     for r in range(world):
         rlo, rhi = shard_range(n_windows, r, world)
         parts.append(bufs[r].view(torch.int16)[:rhi - rlo])
-    return torch.cat(parts)
+    return torch.cat(parts).to(cls_local.device)
 
 
 def decode_capture_sharded(modem, audio_local: torch.Tensor, n_windows: int, timeout: float, max_calls: int,
