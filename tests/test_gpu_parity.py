@@ -385,6 +385,56 @@ def test_detect_every_bin(mb, ma, golden, scheme):
     check_detect(m, top, n, lut)
 
 
+@pytest.mark.parametrize("scheme", ["B", "A"])
+def test_detect_energy_outside_the_searched_bins(mb, ma, golden, scheme):
+    """Nearly all the energy in bin N//2, the one bin np.argmax never looks at, and far below it
+    (a) a noise floor, (b) two tones a millionth apart in amplitude, (c) one clear tone.  The float32
+    error of every searched bin scales with the energy of the whole window, so (a) and (b) can
+    only be decided in float64; the kernel has to notice that from the window's energy, not from
+    the searched bins alone.  Bins, classes and magnitudes must be the oracle's."""
+    m, n, lut = (mb, 7055, golden["classes_b_7055"]) if scheme == "B" else (ma, 2205, golden["classes_a_2205"])
+    lut = np.array(lut, dtype=np.uint16)
+    t = np.arange(n)
+    rng = np.random.default_rng(21)
+    top = 0.4 * np.cos(2 * np.pi * (n // 2) * t / n)
+    wins = []
+    for i in range(6):                                   # (a) noise floor 1e-5
+        wins.append(top + 1e-5 * rng.standard_normal(n))
+    for i in range(6):                                   # (b) near-tie of two weak tones
+        k1, k2 = int(rng.integers(60, n // 2 - 5)), int(rng.integers(60, n // 2 - 5))
+        eps = (1e-6, -1e-6, 3e-6, -3e-6, 1e-5, -1e-5)[i]
+        wins.append(top + 1e-4 * np.cos(2 * np.pi * k1 * t / n + 0.4) + 1e-4 * (1 + eps) * np.cos(2 * np.pi * k2 * t / n + 1.1))
+    for a in (1e-3, 1e-2):                               # (c) clear winner, 400x and 40x below the top bin
+        wins.append(top + a * np.cos(2 * np.pi * 777 * t / n + 0.2))
+    x32 = np.concatenate(wins).astype(np.float32)
+    m.detect_stats()
+    check_detect(m, x32, n, lut)
+    windows, top2, full = m.detect_stats()
+    assert windows == 14 and top2 + full >= 12           # (a) and (b) were not decided in float32
+
+
+def test_detect_float32_error_stays_inside_the_bound(mb):
+    """The flag rests on |dZ| <= 724 u sqrt(E) (u = 2^-24, E = energy of the spectrum) for every
+    float32 output.  Measured here on the reported peak magnitude of windows the float32 pass
+    decided alone: the error must sit far inside that bound."""
+    rng = np.random.default_rng(8)
+    n, t = 7055, np.arange(7055)
+    wins = [0.3 * rng.standard_normal(n) for _ in range(8)]
+    wins += [0.45 * np.cos(2 * np.pi * (350 + 70 * b) * t / 44100) + 0.5 for b in (0, 58, 121, 184, 255)]   # with a DC offset
+    wins += [np.abs(0.9 * rng.standard_normal(n)) for _ in range(3)]                                     # all-positive samples
+    x32 = np.concatenate(wins).astype(np.float32)
+    nwin = len(wins)
+    mb.detect_stats()
+    cls, mag, kbin = mb.detect(dev(np.pad(x32, (0, M.pad4(len(x32)) - len(x32)))), 1, M.pad4(len(x32)), nwin)
+    _, top2, full = mb.detect_stats()
+    spec = np.abs(np.fft.fft(x32.astype(np.float64).reshape(nwin, n), axis=1))[:, :n // 2 + 1]
+    energy = (spec ** 2).sum(axis=1)
+    err = np.abs(mag.cpu().numpy()[0].astype(np.float64) - spec[np.arange(nwin), kbin.cpu().numpy()[0]])
+    bound = 724 * 2.0 ** -24 * np.sqrt(energy)
+    assert top2 + full < nwin                            # some windows were decided in float32
+    assert np.all(err <= bound / 8), (err / bound).max()
+
+
 def test_detect_refinement_paths_forced(golden):
     """Raise the tie band so that the float64 re-evaluation runs on ordinary windows: both
     the two-bin and the whole-spectrum path must reproduce the oracle."""

@@ -124,7 +124,7 @@ int main() {
         printf("%-34s K=%d: %.1f clocks/mfma\n", names[MODE], K, (double)h / ((double)iters * 36)); \
     }
 #define RUNS(MODE) RUN(MODE, 0) RUN(MODE, 2) RUN(MODE, 4) RUN(MODE, 5) RUN(MODE, 6) RUN(MODE, 7) RUN(MODE, 8)
-    RUN(0, 0) RUN(0, 2)
+    RUNS(0) RUNS(1) RUNS(5) RUNS(7) RUNS(8) RUNS(6)
     RUN(11, 2) RUN(11, 4) RUN(11, 8) RUN(12, 1) RUN(12, 2) RUN(12, 4)
     return 0;
 }

@@ -25,6 +25,11 @@ struct wn_ctx {
     int32_t ping_lo, ping_hi;
     // checksum: slicing-by-4 tables [4][256]
     uint32_t *d_crc_tab;
+    // tuning / diagnostic switches, read from the environment once, when the context is made
+    // (WN_DETECT_PROFILE, WN_SYNTH_PER_CU, WN_SYNTH_PART); 0 = not set
+    int detect_profile;
+    int synth_per_cu;
+    long long synth_part;
 };
 
 void wn_set_error(const char *fmt, ...);
@@ -70,5 +75,10 @@ static inline int wn_launch_check(const char *kernel) {
 void wn_host_crc_tables(uint32_t tab[4][256]);
 int wn_plan_lookup(int32_t n, int32_t *n1, int32_t *n2);
 
-// per-file launchers used by wn_ctx.hip at init time
-int wn_detect_prepare(wn_ctx *ctx);
+// Per-device set-up of each kernel file (dynamic-LDS limits of its kernels, addresses of its
+// device symbols).  wn_scheme_init calls them once per device, with that device current, under
+// one lock; launches never change process-wide state.
+int wn_detect_device_setup(int device);
+int wn_sync_device_setup(int device);
+int wn_synth_device_setup(int device);
+int wn_crc_device_setup(int device);

@@ -208,6 +208,15 @@ __global__ __launch_bounds__(CRC_BLOCK) void frame_build_kernel(const uint8_t *_
     }
 }
 
+// the tiled kernel for any stride stages 256 rows of up to 512 + 4 bytes next to the tables: allow that much
+int wn_crc_device_setup(int) {
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_rows_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   4096 + CRC_WAVES * 64 * (512 + 4)));
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_rows_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   4096 + CRC_WAVES * 64 * (512 + 4)));
+    return WN_OK;
+}
+
 template <int MODE>
 static int launch_rows(wn_ctx *ctx, const uint8_t *rows, const int32_t *lens, int32_t stride, int64_t n,
                        uint32_t *out32, wn_frame_rec *out_rec, hipStream_t st) {
@@ -220,12 +229,6 @@ static int launch_rows(wn_ctx *ctx, const uint8_t *rows, const int32_t *lens, in
         long long blocks = (tiles + CRC_WAVES - 1) / CRC_WAVES;
         const long long cap = (long long)ctx->num_cus * 8;
         if (blocks > cap) blocks = cap;
-        static size_t attr_lds[WN_MAX_DEVICES];   // largest dynamic LDS size allowed so far, per device
-        if (lds > 48 * 1024 && lds > attr_lds[ctx->device]) {
-            WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_rows_kernel<MODE, 0>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_lds[ctx->device] = lds;
-        }
         if (stride == 128)
             hipLaunchKernelGGL((crc_rows_kernel<MODE, 8>), dim3((unsigned)blocks), dim3(CRC_BLOCK), lds, st, rows, lens,
                                (int)stride, (long long)n, ctx->d_crc_tab, out32, out_rec);

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -303,7 +304,28 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
     }
     INIT_HIP(hipMalloc((void **)&ctx->d_stats, 4 * sizeof(unsigned long long)));
     INIT_HIP(hipMemset(ctx->d_stats, 0, 4 * sizeof(unsigned long long)));
-    INIT_TRY(wn_detect_prepare(ctx));
+    if ((size_t)ctx->n * sizeof(double2) > 150 * 1024) {
+        wn_set_error("window length %d too large for the float64 phase table", ctx->n);
+        wn_ctx_destroy(ctx);
+        return WN_ERR_UNSUPPORTED;
+    }
+    if (const char *e = getenv("WN_DETECT_PROFILE")) ctx->detect_profile = atoi(e) != 0;
+    if (const char *e = getenv("WN_SYNTH_PER_CU")) ctx->synth_per_cu = atoi(e);
+    if (const char *e = getenv("WN_SYNTH_PART")) ctx->synth_part = atoll(e);
+    {
+        // everything that is per device and process-wide happens here, once, under a lock:
+        // afterwards launches from any number of threads only read
+        static std::mutex mu;
+        static bool ready[WN_MAX_DEVICES];
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ready[ctx->device]) {
+            INIT_TRY(wn_detect_device_setup(ctx->device));
+            INIT_TRY(wn_sync_device_setup(ctx->device));
+            INIT_TRY(wn_synth_device_setup(ctx->device));
+            INIT_TRY(wn_crc_device_setup(ctx->device));
+            ready[ctx->device] = true;
+        }
+    }
     *out = ctx;
     return WN_OK;
 }

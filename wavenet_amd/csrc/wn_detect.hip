@@ -176,12 +176,19 @@ __device__ __forceinline__ unsigned dpp_u(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xF, false);
 }
 
+// the DPP-selected lane's value where the row mask writes, 0 elsewhere
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_f0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false));
+}
+
 template <int N1, int N2, bool PROF>
 __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict__ audio, long long n_streams,
                                                         long long stream_stride, long long first_sample,
                                                         long long n_windows, const float2 *__restrict__ g_tw1,
                                                         const float2 *__restrict__ g_tw2,
                                                         const uint16_t *__restrict__ lut, float keep,
+                                                        float err_lin, float err_sq,
                                                         uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
                                                         int32_t *__restrict__ out_bin) {
     typedef Plan<N1, N2> P;
@@ -432,6 +439,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         Top3 best;
         best.k1 = best.k2 = best.k3 = 0u;
         best.mx = 0u;
+        floatx2 esum = {0.f, 0.f};   // sum of |Z|^2 over this lane's outputs (the excluded bin included)
         static_for<TA>([&](auto TT) {
             constexpr int tt = decltype(TT)::value;
             floatx4 acc[4][C2T];   // the sums A, B, C, E
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     const floatx2 Cc = hf ? acc[2][c].hi : acc[2][c].lo, E = hf ? acc[3][c].hi : acc[3][c].lo;
                     const floatx2 rp = A + B, rm = A - B, ip = Cc - E, im = Cc + E;
                     const floatx2 mp2 = rp * rp + ip * ip, mm2 = rm * rm + im * im;
+                    esum += mp2 + mm2;
                     static_for<2>([&](auto EL) {
                         constexpr int r = 2 * hf + decltype(EL)::value;
                         float mp = mp2[decltype(EL)::value], mm = mm2[decltype(EL)::value];
@@ -488,15 +497,19 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // sixteens merge two disjoint lane sets each and leave every lane of a row with the
         // row's result; two row broadcasts then collect the four rows in the last row (the
         // other rows merge with themselves and are not used).  Lane 63 decides and stores.
-        auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, unsigned om) {
+        float etot = esum.x + esum.y;
+        auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, unsigned om, float oe) {
             best.mx = max(best.mx, om);
             top3_insert(best, o1);
             top3_insert(best, o2);
             top3_insert(best, o3);
+            etot += oe;
         };
+        // the energy of the other lane set rides along; in the two broadcast steps a row that is not
+        // written keeps its own partial sum, and lane 63 ends with the sum over the wave
 #define WN_MERGE_DPP(CTRL, ROWS)                                                                        \
     merge_with(dpp_u<CTRL, ROWS>(best.k1), dpp_u<CTRL, ROWS>(best.k2), dpp_u<CTRL, ROWS>(best.k3),     \
-               dpp_u<CTRL, ROWS>(best.mx))
+               dpp_u<CTRL, ROWS>(best.mx), dpp_f0<CTRL, ROWS>(etot))
         WN_MERGE_DPP(0xB1, 0xF);    // quad_perm [1,0,3,2]
         WN_MERGE_DPP(0x4E, 0xF);    // quad_perm [2,3,0,1]
         WN_MERGE_DPP(0x141, 0xF);   // row_half_mirror
@@ -505,14 +518,24 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         WN_MERGE_DPP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
 #undef WN_MERGE_DPP
         {
-            // A largest |Z|^2 outside [1e-30, 1e30] (zero, or samples so small or so large that
-            // float32 squares lose their meaning, or not a number) is not decided here: the
-            // window goes to the float64 pass, which also recognises all-zero windows.
+            // A largest |Z|^2 below 1e-30 or a total energy above 1e30 (zero, or samples so small or
+            // so large that float32 squares lose their meaning, or not a number) is not decided
+            // here: the window goes to the float64 pass, which also recognises all-zero windows.
             const float mxf = __uint_as_float(best.mx);
-            const bool odd = !(mxf >= 1e-30f && mxf <= 1e30f);
+            const bool odd = !(mxf >= 1e-30f && etot <= 1e30f);
+            // Keys carry |Z|^2 truncated to 2^-11 relative.  The float32 value of every |Z|^2 is
+            // within err_lin*sqrt(|Z|^2 * E) + err_sq*E of the exact one (E = energy of the whole
+            // spectrum, of which etot is an upper bound up to rounding; derivation at launch_detect),
+            // so a bin whose key value, rounded up, reaches `lim` may be the true maximum.
             const float f1 = __uint_as_float(best.k1 & ~KEY_BIN), f2 = __uint_as_float(best.k2 & ~KEY_BIN),
                         f3 = __uint_as_float(best.k3 & ~KEY_BIN);
-            const bool full = odd | (f3 >= f1 * keep), top2 = f2 >= f1 * keep;
+            const float lim = (f1 - (err_lin * (sqrtf(mxf) * sqrtf(etot)) + err_sq * etot)) * keep;
+            // The magnitude that is reported must hold to 1e-4 relative as well.  Its float32 error
+            // is a few 1e-9 * sqrt(E) in practice (measured; the bound above is the worst case), so
+            // a searched maximum holding less than 1e-6 of the energy (nearly everything sits in the
+            // one bin that is not searched) is recomputed in float64 too.
+            const bool faint = etot > 1e6f * mxf;
+            const bool full = odd | faint | (f3 >= lim), top2 = f2 >= lim;
             const int b = (int)(best.k1 & KEY_BIN);
             const unsigned cls = lut_s[odd ? 0 : b];
             pend_bin = full ? ((odd ? 0 : b) | FLAG_FULL) : (top2 ? (b | FLAG_TOP2) : b);
@@ -664,18 +687,8 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
                          int64_t stream_stride, int64_t first_sample, int64_t n_windows, uint16_t *d_cls,
                          float *d_mag, int32_t *d_bin, hipStream_t st) {
     typedef Plan<N1, N2> P;
-    static bool attr_done[WN_MAX_DEVICES];
-    bool &attr = attr_done[ctx->device];
-    if (!attr) {
-        WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS));
-        WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::LDS));
-        attr = true;
-    }
-    // WN_DETECT_PROFILE=1 (diagnostics, results are not usable): per-phase clock counts of wave 0
-    // in out_bin[0..8]
-    const bool prof = getenv("WN_DETECT_PROFILE") && atoi(getenv("WN_DETECT_PROFILE")) != 0;
+    // ctx->detect_profile (WN_DETECT_PROFILE=1 when the context was made; diagnostics, results
+    // are not usable): per-phase clock counts of wave 0 in out_bin[0..8]
     const long long total = n_streams * n_windows;
     // one workgroup per CU for the long window (its four window buffers fill the LDS); short
     // windows leave room for two, and a second wave per SIMD runs its vector-ALU work under
@@ -683,52 +696,77 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     constexpr int PER_CU = (2 * P::LDS <= 160 * 1024 && 2 * (P::TA * 16 + 160) <= 512) ? 2 : 1;
     long long blocks = (total + 3) / 4;
     if (blocks > (long long)ctx->num_cus * PER_CU) blocks = (long long)ctx->num_cus * PER_CU;
-    // squared magnitudes are compared, through keys that drop up to 2^-11 of the value
+    // Which windows the float32 spectrum may decide.  u = 2^-24.  A folded sample (sum or
+    // difference of four samples, two roundings) is within 2u of exact relative to the sum q of
+    // the four magnitudes; a stage-1 output adds a rounded twiddle (u) and at most 4*KS1 <= 44
+    // accumulation steps (taken as 2u each: faithful rounding is enough): 91u * (q summed over the
+    // row pair).  A stage-2 sum repeats that on the stage-1 outputs (89u) and carries their error
+    // (91u): 180u * ||x||_1 for each of the four real sums; real and imaginary part of an output
+    // combine two sums each (one more rounding): 362u * ||x||_1, so |dZ| <= 512u * ||x||_1
+    // <= 512u * sqrt(N * sum x^2) <= 512u * sqrt(2E), E = sum of |Z|^2 over bins [0, N/2]
+    // (N odd: N * sum x^2 = 2E - Z_0^2).  With B = 724u * sqrt(E):
+    //   | |Z^|^2 - |Z|^2 | <= 2|Z|B + B^2 (+ 3u|Z|^2 for squaring and adding),
+    // and two bins are ordered for certain when their float32 values differ by more than the sum
+    // of both terms: 4B*sqrt(m1) + 2B^2 + 6u*m1.  The kernel's E is summed in float32 from the
+    // float32 outputs (self-mirrored outputs counted twice, which only raises it); it can fall
+    // short of the exact E by under 1 %, which the factors below absorb.
+    const double u = ldexp(1.0, -24), cB = 724.0 * u * 1.01;
+    const float err_lin = (float)(4.0 * cB), err_sq = (float)(2.0 * cB * cB + 6.0 * u);
+    // keys drop up to 2^-11 of a value; ctx->tie_band widens the band further (tests force the
+    // float64 path with it): magnitudes within that relative distance count as tied
     const double k = (1.0 - ctx->tie_band) * (1.0 - ctx->tie_band) / (1.0 + 1.0 / 2048.0) * (1.0 - 1e-6);
-    if (prof)
+    if (ctx->detect_profile)
         hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
-                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, d_cls, d_mag,
-                           d_bin);
+                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq,
+                           d_cls, d_mag, d_bin);
     else
         hipLaunchKernelGGL((detect_kernel<N1, N2, false>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
-                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, d_cls, d_mag,
-                           d_bin);
+                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq,
+                           d_cls, d_mag, d_bin);
     return wn_launch_check("detect_kernel");
 }
 
-int wn_detect_prepare(wn_ctx *ctx) {
-    // the float64 phase table of the re-evaluation kernel lives in dynamic LDS
-    const size_t lds = (size_t)ctx->n * sizeof(double2);
-    if (lds > 150 * 1024) {
-        wn_set_error("window length %d too large for the float64 phase table", ctx->n);
-        return WN_ERR_UNSUPPORTED;
-    }
-    WN_HIP_TRY(hipFuncSetAttribute((const void *)refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+template <int N1, int N2>
+static int detect_attr() {
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Plan<N1, N2>::LDS));
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, true>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Plan<N1, N2>::LDS));
     return WN_OK;
 }
 
-extern "C" int wn_detect_windows(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
-                                 int64_t stream_stride, int64_t first_sample, int64_t n_windows, uint16_t *d_cls,
-                                 float *d_peak_mag, int32_t *d_peak_bin, void *stream) {
-    WN_REQUIRE(ctx && n_streams >= 0 && n_windows >= 0 && first_sample >= 0 && stream_stride >= 0, "ctx / sizes");
-    if (n_streams == 0 || n_windows == 0) return WN_OK;
-    WN_REQUIRE_DEVICE(ctx);
-    WN_REQUIRE(d_audio && d_cls && d_peak_mag && d_peak_bin, "null device pointer");
+int wn_detect_device_setup(int device) {
+    int rc = detect_attr<83, 85>();
+    if (rc == WN_OK) rc = detect_attr<45, 49>();
+    if (rc != WN_OK) return rc;
+    // the float64 phase table of the re-evaluation kernel lives in dynamic LDS: window length x 16
+    // bytes (wn_scheme_init refuses windows whose table would not fit)
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   150 * 1024));
+    (void)device;
+    return WN_OK;
+}
+
+// Argument checks and the two launches shared by both entry points: `d_mag`, `d_bin` hold the
+// per-window magnitude and bin (and, between the two kernels, the flags of the windows the second
+// one re-evaluates), `stats` the four counters of the float64 pass.
+static int detect_run(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
+                      int64_t stream_stride, int64_t first_sample, int64_t n_windows, uint16_t *d_cls, float *d_mag,
+                      int32_t *d_bin, unsigned long long *stats, hipStream_t st) {
+    WN_REQUIRE(d_audio && d_cls && d_mag && d_bin, "null device pointer");
     WN_REQUIRE(((uintptr_t)d_audio % 16) == 0 && audio_len % 4 == 0, "d_audio 16-byte aligned, audio_len % 4 == 0");
     const int64_t span = first_sample + n_windows * (int64_t)ctx->n;
     WN_REQUIRE(n_streams == 1 || span <= stream_stride, "windows of a stream overlap the next stream");
     WN_REQUIRE((n_streams - 1) * stream_stride + span <= audio_len, "windows reach past audio_len");
-    hipStream_t st = (hipStream_t)stream;
     int rc;
     if (ctx->n1 == 83 && ctx->n2 == 85)
         rc = launch_detect<83, 85>(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls,
-                                   d_peak_mag, d_peak_bin, st);
+                                   d_mag, d_bin, st);
     else if (ctx->n1 == 45 && ctx->n2 == 49)
         rc = launch_detect<45, 49>(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls,
-                                   d_peak_mag, d_peak_bin, st);
+                                   d_mag, d_bin, st);
     else {
         wn_set_error("no detection kernel for %d x %d", ctx->n1, ctx->n2);
         return WN_ERR_UNSUPPORTED;
@@ -740,8 +778,18 @@ extern "C" int wn_detect_windows(wn_ctx *ctx, const float *d_audio, int64_t audi
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(refine_kernel, dim3((unsigned)blocks), dim3(256), (size_t)ctx->n * sizeof(double2), st,
                        d_audio, (long long)n_streams, (long long)stream_stride, (long long)first_sample,
-                       (long long)n_windows, ctx->n, ctx->d_cls_lut, d_cls, d_peak_mag, d_peak_bin, ctx->d_stats);
+                       (long long)n_windows, ctx->n, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats);
     return wn_launch_check("refine_kernel");
+}
+
+extern "C" int wn_detect_windows(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
+                                 int64_t stream_stride, int64_t first_sample, int64_t n_windows, uint16_t *d_cls,
+                                 float *d_peak_mag, int32_t *d_peak_bin, void *stream) {
+    WN_REQUIRE(ctx && n_streams >= 0 && n_windows >= 0 && first_sample >= 0 && stream_stride >= 0, "ctx / sizes");
+    if (n_streams == 0 || n_windows == 0) return WN_OK;
+    WN_REQUIRE_DEVICE(ctx);
+    return detect_run(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls, d_peak_mag,
+                      d_peak_bin, ctx->d_stats, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -290,6 +290,14 @@ __global__ __launch_bounds__(256, 1) void sync_kernel(const float *__restrict__ 
     flush();
 }
 
+int wn_sync_device_setup(int) {
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)sync_kernel<7055>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)SyncPlan<7055>::LDS));
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)sync_kernel<2205>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)SyncPlan<2205>::LDS));
+    return WN_OK;
+}
+
 extern "C" int wn_sync_scan(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
                             int64_t stream_stride, int64_t first_sample, int64_t n_windows, float *d_ping_energy,
                             float *d_win_energy, uint8_t *d_verdict, void *stream) {
@@ -334,14 +342,6 @@ extern "C" int wn_sync_scan(wn_ctx *ctx, const float *d_audio, int64_t audio_len
     const long long total = n_streams * n_windows;
     long long blocks = (total + 3) / 4;
     if (blocks > ctx->num_cus) blocks = ctx->num_cus;
-    static bool attr_done[WN_MAX_DEVICES];
-    if (!attr_done[ctx->device]) {
-        WN_HIP_TRY(hipFuncSetAttribute((const void *)sync_kernel<7055>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)SyncPlan<7055>::LDS));
-        WN_HIP_TRY(hipFuncSetAttribute((const void *)sync_kernel<2205>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)SyncPlan<2205>::LDS));
-        attr_done[ctx->device] = true;
-    }
     if (N == 7055)
         hipLaunchKernelGGL(sync_kernel<7055>, dim3((unsigned)blocks), dim3(256), SyncPlan<7055>::LDS,
                            (hipStream_t)stream, d_audio, (long long)n_streams, (long long)stream_stride,

@@ -367,6 +367,16 @@ extern "C" int wn_synth_layout(wn_ctx *ctx, const uint8_t *d_frames, const int32
     return wn_launch_check("synth_layout_kernel");
 }
 
+// the dynamic LDS of synth_kernel depends on the scheme's sample rate and is checked against
+// 150 KB at launch: allow that much once
+int wn_synth_device_setup(int) {
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   150 * 1024));
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   150 * 1024));
+    return WN_OK;
+}
+
 extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uint16_t *d_seg_freq,
                               const int32_t *d_n_segs, int32_t seg_cap, int64_t n, const int64_t *d_dst_off,
                               const int64_t *d_fill_to, int64_t slot_len, void *d_audio, int64_t audio_len,
@@ -386,10 +396,8 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    if (const char *e = getenv("WN_SYNTH_PER_CU")) {
-        const int v = atoi(e);
+    if (const int v = ctx->synth_per_cu)
         if (v >= 1 && v <= 2048 / SYN_BLOCK && (size_t)v * lds <= 160 * 1024) per_cu = v;
-    }
     const long long resident = (long long)ctx->num_cus * per_cu;
     // Large parts amortise the per-part set-up (segment table, first tone): 192 Ki samples
     // (768 KB) when there is enough work for every resident workgroup four times over, smaller
@@ -398,10 +406,7 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     // WN_SYNTH_PART / WN_SYNTH_PER_CU override the choice for tuning.
     long long part_want = (n * slot_len / (resident * 4) + 4095) & ~4095ll;
     part_want = part_want < 16384 ? 16384 : (part_want > 196608 ? 196608 : part_want);
-    if (const char *e = getenv("WN_SYNTH_PART")) {
-        const long long v = atoll(e);
-        if (v >= 4096) part_want = v;
-    }
+    if (ctx->synth_part >= 4096) part_want = ctx->synth_part;
     long long parts = (slot_len + part_want - 1) / part_want;
     if (parts < 1) parts = 1;
     long long part_len = (slot_len + parts - 1) / parts;
@@ -410,24 +415,12 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     const long long items = n * parts;
     const long long blocks = items < resident ? items : resident;
     hipStream_t st = (hipStream_t)stream;
-    static size_t attr_lds[2][WN_MAX_DEVICES];   // largest dynamic LDS size allowed so far, per format and device
-    size_t &attr = attr_lds[fmt == WN_FMT_F32 ? 0 : 1][ctx->device];
     if (fmt == WN_FMT_F32) {
-        if (lds > attr) {
-            WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<float>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = lds;
-        }
         hipLaunchKernelGGL(synth_kernel<float>, dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,
                            d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,
                            (const long long *)d_dst_off, (const long long *)d_fill_to, (float *)d_audio,
                            (long long)audio_len, (const float *)ctx->d_sin_f32, ctx->quarter, (int)tab_entries);
     } else {
-        if (lds > attr) {
-            WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<int16_t>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr = lds;
-        }
         hipLaunchKernelGGL(synth_kernel<int16_t>, dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,
                            d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,
                            (const long long *)d_dst_off, (const long long *)d_fill_to, (int16_t *)d_audio,
