@@ -165,6 +165,20 @@ int wn_detect_windows(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int6
                       int64_t stream_stride, int64_t first_sample, int64_t n_windows,
                       uint16_t *d_cls, float *d_peak_mag, int32_t *d_peak_bin, void *stream);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory or let a
+ * library do so (code under HIP graph capture, tight serving loops, harnesses that forbid it) and
+ * that only need the class words: wn_detect_windows without the magnitude and bin outputs.  What
+ * that call keeps in them between its two kernels, and its counters, live here in a workspace
+ * inside the library (one array per GPU, 8 MiB + 256 bytes, held until the process ends), so
+ * the call makes no allocation of any kind.  At most WN_DETECT_NOALLOC_MAX_WINDOWS windows
+ * (n_streams * n_windows) per call; more is refused with WN_ERR_ARG.  d_cls equals what
+ * wn_detect_windows writes.  Calls on one GPU share the workspace: they must not overlap in time
+ * (not on two streams, not from two threads); the counters are not reported. */
+#define WN_DETECT_NOALLOC_MAX_WINDOWS (1 << 20)
+int wn_detect_windows_noalloc(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
+                              int64_t stream_stride, int64_t first_sample, int64_t n_windows,
+                              uint16_t *d_cls, void *stream);
+
 /* ---- K3: frame sync ----------------------------------------------------------------- */
 /* Sync-tone correlator over the same window grid: per window the energy sum(x^2), the
  * largest |X_k|^2 over the ping bins, and a verdict on "dominant bin is a ping bin"

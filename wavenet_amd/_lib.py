@@ -36,6 +36,7 @@ ST_OK, ST_EMPTY, ST_SHORT_HEADER, ST_SHORT_BODY = 0, 1, 2, 3
 END_EOF, END_TIMEOUT, END_OVERFLOW = 0, 1, 0x100
 EMIT_LIVE, EMIT_WAV = 0, 1
 FMT_F32, FMT_I16 = 0, 1
+DETECT_NOALLOC_MAX_WINDOWS = 1 << 20
 
 _vp, _i32, _i64, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 _P = C.POINTER
@@ -59,6 +60,7 @@ SIGNATURES = {
     "wn_synth_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _vp]),
     "wn_channel_awgn": (C.c_int, [_vp, _vp, _i64, C.c_float, _u64, _vp]),
     "wn_detect_windows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "wn_detect_windows_noalloc": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "wn_sync_scan": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "wn_slice_frames": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wn_selftest_mfma": (C.c_int, [_vp, _vp]),

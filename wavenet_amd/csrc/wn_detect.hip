@@ -728,6 +728,14 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     return wn_launch_check("detect_kernel");
 }
 
+// Workspace of wn_detect_windows_noalloc: what wn_detect_windows keeps in the caller's magnitude
+// and bin arrays and in the context's counter block.  Every GPU holds its own copy of the array
+// at its own address; host code never uses the array's name as an address, only the pointer
+// hipGetSymbolAddress returned for the device in question.
+#define NOALLOC_HEAD 256   // bytes: the four counters of the float64 pass, padded
+static __device__ __align__(256) unsigned char scratch[NOALLOC_HEAD + 8ull * WN_DETECT_NOALLOC_MAX_WINDOWS];
+static unsigned char *g_scratch_ptr[WN_MAX_DEVICES];   // written once per device, under wn_scheme_init's lock
+
 template <int N1, int N2>
 static int detect_attr() {
     WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, false>,
@@ -745,7 +753,14 @@ int wn_detect_device_setup(int device) {
     // bytes (wn_scheme_init refuses windows whose table would not fit)
     WN_HIP_TRY(hipFuncSetAttribute((const void *)refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    150 * 1024));
-    (void)device;
+    // called with `device` current: the address of this device's copy of the workspace
+    void *p = nullptr;
+    WN_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p || ((uintptr_t)p % 256) != 0) {
+        wn_set_error("workspace symbol of device %d resolved to %p", device, p);
+        return WN_ERR_HIP;
+    }
+    g_scratch_ptr[device] = (unsigned char *)p;
     return WN_OK;
 }
 
@@ -790,6 +805,37 @@ extern "C" int wn_detect_windows(wn_ctx *ctx, const float *d_audio, int64_t audi
     WN_REQUIRE_DEVICE(ctx);
     return detect_run(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls, d_peak_mag,
                       d_peak_bin, ctx->d_stats, (hipStream_t)stream);
+}
+
+// The same two kernels with the per-window magnitude and bin arrays and the counters in the
+// library's own per-device workspace: no allocation of any kind happens in the call.  Calls on
+// one GPU share that workspace and must not overlap.
+extern "C" int wn_detect_windows_noalloc(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
+                                         int64_t stream_stride, int64_t first_sample, int64_t n_windows,
+                                         uint16_t *d_cls, void *stream) {
+    WN_REQUIRE(ctx && n_streams >= 0 && n_windows >= 0 && first_sample >= 0 && stream_stride >= 0, "ctx / sizes");
+    if (n_streams == 0 || n_windows == 0) return WN_OK;
+    if (n_streams > WN_DETECT_NOALLOC_MAX_WINDOWS || n_windows > WN_DETECT_NOALLOC_MAX_WINDOWS ||
+        n_streams * n_windows > WN_DETECT_NOALLOC_MAX_WINDOWS) {
+        wn_set_error("bad argument: %lld x %lld windows exceed the %d windows the library's workspace holds; "
+                     "split the call or use wn_detect_windows",
+                     (long long)n_streams, (long long)n_windows, WN_DETECT_NOALLOC_MAX_WINDOWS);
+        return WN_ERR_ARG;
+    }
+    WN_REQUIRE_DEVICE(ctx);
+    unsigned char *ws = g_scratch_ptr[ctx->device];
+    if (!ws) {
+        wn_set_error("workspace of device %d was not set up", ctx->device);
+        return WN_ERR_HIP;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // the counters start at zero in every call; magnitudes and bins are written for every window
+    // of the call before they are read, so what the previous call left there does not matter
+    WN_HIP_TRY(hipMemsetAsync(ws, 0, NOALLOC_HEAD, st));
+    int32_t *bins = (int32_t *)(ws + NOALLOC_HEAD);
+    float *mags = (float *)(ws + NOALLOC_HEAD + 4ull * WN_DETECT_NOALLOC_MAX_WINDOWS);
+    return detect_run(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls, mags, bins,
+                      (unsigned long long *)ws, st);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -196,6 +196,18 @@ class Modem:
                                         n_windows, _ptr(cls), _ptr(mag), _ptr(kbin), _stream()), "wn_detect_windows")
         return cls, mag, kbin
 
+    def detect_classes_into(self, audio: torch.Tensor, n_streams: int, stream_stride: int, n_windows: int,
+                            cls: torch.Tensor, first_sample: int = 0):
+        """The class words of detect() written into a tensor the caller already holds, through the
+        entry point that allocates nothing (for graph capture and serving loops); at most
+        DETECT_NOALLOC_MAX_WINDOWS windows per call, calls on one GPU must not overlap."""
+        assert audio.dtype == torch.float32 and audio.is_contiguous()
+        assert cls.dtype == torch.int16 and cls.is_contiguous() and cls.numel() >= n_streams * n_windows
+        L.check(L.lib.wn_detect_windows_noalloc(self._ctx, _ptr(audio), audio.numel(), n_streams, stream_stride,
+                                                first_sample, n_windows, _ptr(cls), _stream()),
+                "wn_detect_windows_noalloc")
+        return cls
+
     def set_tie_band(self, rel: float):
         L.check(L.lib.wn_detect_set_tie_band(self._ctx, float(rel)), "wn_detect_set_tie_band")
 
