@@ -14,8 +14,13 @@
  *    of a torch tensor); everything else is host memory.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
  *    enqueue work; they do not synchronise unless stated.
- *  - A wn_ctx is immutable after wn_scheme_init and may be shared by threads; use one
- *    stream per thread for concurrent calls.
+ *  - Threads.  wn_scheme_init does everything that is per device and process-wide (kernel
+ *    attributes, symbol addresses) under a lock, and reads the environment switches once; the
+ *    calls that launch work only read the context.  A wn_ctx may therefore be shared by threads,
+ *    each enqueueing on its own stream.  Exceptions, all stated at their declarations:
+ *    wn_detect_set_tie_band changes the context (a set-up call: not while another thread
+ *    detects with it), the counters read by wn_detect_stats are summed over all callers of the
+ *    context, and wn_detect_windows_noalloc calls on one GPU must not overlap.
  */
 #ifndef WAVENET_HIP_H
 #define WAVENET_HIP_H
@@ -106,12 +111,15 @@ int64_t wn_host_frame_samples(const wn_scheme *s, const uint8_t *frame, int32_t 
 /* Builds the device-side tables for one scheme on the current device. */
 int wn_scheme_init(const wn_scheme *s, wn_ctx **out);
 int wn_ctx_destroy(wn_ctx *ctx);
-/* Relative band under which the two largest bins of a window are re-evaluated in
- * float64 (default 5e-5).  Tests raise it to force that path. */
+/* Extra relative band (on magnitudes) under which the largest bins of a window count as tied
+ * and are re-evaluated in float64, on top of the error bound the kernel applies by itself
+ * (default 0).  Tests raise it to force that path.  Changes the context: call it before the
+ * context is shared, not concurrently with detection on it. */
 int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
 /* Counters since the last call (synchronises `stream`): out[0] windows detected,
  * out[1] windows whose top two bins were re-evaluated in float64, out[2] windows whose
- * whole spectrum was. */
+ * whole spectrum was.  One set of counters per context, summed over every thread and stream
+ * that detects with it. */
 int wn_detect_stats(wn_ctx *ctx, int64_t out[3], void *stream);
 
 /* ---- K4: checksum and frames ------------------------------------------------------- */

@@ -529,6 +529,58 @@ def test_slice_random_class_sequences(mb):
                 assert bool(reason[s, j] & L.END_OVERFLOW) == (len(b) > 64)
 
 
+def test_slice_long_frames_across_chunk_boundaries(mb):
+    """The kernel walks the class words 64 windows at a time.  Long frames (hundreds of windows
+    between ping and EOF) whose runs of byte windows and separators straddle every multiple of 64
+    at every phase, timeouts that end in the middle of a chunk, an EOF in the same chunk as a
+    symbol, a ping as the last window of a chunk: all must equal the oracle's sequential loop."""
+    rng = np.random.default_rng(17)
+    NONE, PING, EOF = 256, 256 | 512, 256 | 1024
+    rows = []
+    for s in range(192):
+        lead = s % 67                                  # the ping lands on every position of a chunk
+        seq = [NONE] * lead + [PING]
+        n_sym = 20 + s % 50
+        for i in range(n_sym):
+            seq += [NONE] * int(rng.integers(1, 4))    # separator windows
+            seq += [int(rng.integers(0, 256))] * int(rng.integers(1, 6))   # the same tone over several windows
+        if s % 3 == 0:
+            seq += [int(rng.integers(0, 256)), EOF]    # symbol without separator right before the EOF
+        elif s % 3 == 1:
+            seq += [NONE, EOF]
+        # s % 3 == 2: no EOF, the call ends by timeout or at the end of the capture
+        seq += [NONE] * 5 + [PING, NONE, 65, NONE, 66, 66, NONE, EOF]      # a second, short frame
+        rows.append(seq)
+    n_windows = max(len(r) for r in rows) + 3
+    cls = np.full((len(rows), n_windows), NONE, dtype=np.uint16)
+    for i, r in enumerate(rows):
+        cls[i, :len(r)] = r
+    for tw, max_calls in ((1000, 4), (97, 8), (64, 8), (63, 10), (130, 6)):
+        by, lens, start, end, reason, ncalls = [t.cpu().numpy() for t in
+                                                mb.slice(dev(cls.astype(np.int16)), tw, max_calls, 128)]
+        for s in range(len(rows)):
+            want = mo.slice_classes(cls[s], tw, max_calls)
+            assert ncalls[s] == len(want), (s, tw)
+            for j, (w0, w1, b, r) in enumerate(want):
+                assert (start[s, j], end[s, j], reason[s, j] & 0xFF) == (w0, w1, r), (s, tw, j)
+                assert bytes(by[s, j, :lens[s, j]]) == b[:128], (s, tw, j)
+
+
+def test_contexts_of_both_schemes_on_one_device(golden):
+    """Making the short-window context after the long-window one must leave the long one fully
+    usable, its float64 pass (whose phase table is the largest dynamic LDS request) included."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    b = M.Modem(M.esquema_b())
+    a = M.Modem(M.esquema_a())
+    b.set_tie_band(0.5)
+    x = capture_of(golden["listen_b"][0])[:7055 * 10].astype(np.float32)
+    b.detect_stats()
+    check_detect(b, x, 7055, lut)
+    assert b.detect_stats()[1] > 0
+    xa = np.concatenate([mo.tone(f, n, d, SA) for f, n, d in mo.schedule(b"ab", SA)]).astype(np.float32)
+    check_detect(a, xa, 2205, np.array(golden["classes_a_2205"], dtype=np.uint16))
+
+
 # ------------------------------------------------------------------------------- K3
 def test_sync_scan_energies_and_sound_verdicts(mb, golden):
     """Energies within 1e-4 relative of the float64 values; a decided verdict is never wrong."""

@@ -235,7 +235,7 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
     ctx->e1 = n2 * inv_mod(n2, n1);
     ctx->e2 = n1 * inv_mod(n1, n2);
     ctx->quarter = s->sample_rate / 4;
-    ctx->tie_band = 5e-5;
+    ctx->tie_band = 0.0;
 
 #define INIT_TRY(expr)            \
     do {                          \

@@ -42,13 +42,16 @@
 // Bound: matrix cores (f32 MFMA, 64 FLOP/clk/SIMD).
 //
 // Decisions must equal the reference's float64 FFT.  The per-lane running top three are
-// kept as integer keys (|Z|^2 bits with the low 12 bits replaced by the bin), so windows
-// whose largest bins are closer than the relative band (default 5e-5, ~10x the f32 error)
-// plus the 2^-12 the keys drop are re-evaluated in float64: the two candidate bins by
-// direct summation with exactly reduced phases; if a third bin is in the band too, the
-// whole spectrum.  Windows whose largest |Z|^2 is zero or outside [1e-30, 1e30] take the
-// float64 path too (all-zero windows end there without a spectrum), so the result does not
-// depend on how loud the capture is.
+// kept as integer keys (|Z|^2 bits with the low 12 bits replaced by the bin), and the kernel
+// sums |Z|^2 over all its outputs: by Parseval that is the energy of the window, and the
+// float32 error of every output is bounded by a multiple of its square root (derivation at
+// launch_detect).  Windows whose runner-up comes within that bound of the largest bin (plus
+// the 2^-11 the keys drop) are re-evaluated in float64: the two candidate bins by direct
+// summation with exactly reduced phases; if a third bin is that close too, the whole
+// spectrum.  Windows whose largest |Z|^2 is zero or below 1e-30, whose energy is above 1e30,
+// or whose searched maximum holds less than 1e-6 of the energy take the float64 path too
+// (all-zero windows end there without a spectrum), so the result does not depend on how loud
+// the capture is or on where its energy sits.
 #include <math.h>
 #include <stdlib.h>
 
