@@ -76,6 +76,23 @@ def test_trama_build_parse_and_errors(cs, golden):
     assert cs.freq_to_byte(200) is None and cs.freq_to_byte(18300.0) is None
 
 
+def test_reference_quirks_are_kept(cs):
+    """Two behaviours of the reference a port might 'fix': addresses that are not 6 bytes long are
+    concatenated as they are (c1_shared.py:109-111; the checksum is zlib's over what was built), and
+    escuchar_archivo calls .imprimir() on -1 after three failed listens (c1_communication.py:27-34)."""
+    import zlib
+
+    from wavenet_amd.dispositivo_wavenet import c1_communication
+    t = cs.Trama(version=1, mac_origen=b"\xaa\xbb", mac_destino=b"\x01\x02\x03\x04\x05\x06\x07", tipo=3, payload=b"hola")
+    body = bytes([1]) + b"\xaa\xbb" + b"\x01\x02\x03\x04\x05\x06\x07" + bytes([3, 4]) + b"hola"
+    assert t.get_bytes() == body + zlib.crc32(body).to_bytes(4, "big") and bytes(t.checksum) == t.get_bytes()[-4:]
+    with pytest.raises(ValueError):
+        cs.Trama(version=256, mac_origen=MAC_O, mac_destino=MAC_D, tipo=3, payload=b"")
+    cs.canal().cargar(np.zeros(3 * 7055))            # nothing on the channel: every listen fails at once
+    with pytest.raises(AttributeError):
+        c1_communication.escuchar_archivo("11:22:33:44:55:66")
+
+
 def test_string_chunking(cs, golden):
     text = bytes.fromhex(golden["prueba_txt"])
     tramas = cs.obtener_tramas_desde_string(text, "aa:bb:cc:dd:ee:ff", "11:22:33:44:55:66")

@@ -203,8 +203,8 @@ def escuchar_archivo(my_mac_address_str):
     if info is None:
         logging.info("No se escucho ninguna trama con la info del archivo inicial")
         return False
+    info.imprimir()     # after three failed listens `info` is -1 and this raises, as it does in the reference (:27-34)
     try:
-        info.imprimir()
         total, nombre = decodificar_payload_archivo_info(info.payload)
     except Exception as e:
         logging.warning(f"Error al decodificar el payload: {e}")

@@ -137,7 +137,14 @@ class Trama:
         if not (0 <= self.version <= 255 and 0 <= self.tipo <= 255 and self.length <= 255):
             raise ValueError("byte must be in range(0, 256)")
         if len(self.mac_origen) != 6 or len(self.mac_destino) != 6:
-            raise ValueError("las direcciones MAC deben tener 6 bytes")
+            # the reference concatenates addresses of any length (c1_shared.py:109-111); such a
+            # frame does not have the 15-byte header the frame kernel builds, so only its
+            # checksum comes from the GPU
+            cuerpo = bytearray([self.version]) + bytearray(self.mac_origen) + bytearray(self.mac_destino) + \
+                bytearray([self.tipo, self.length]) + bytearray(self.payload)
+            self.checksum = bytearray(calcular_checksum(cuerpo))
+            self.bytes_trama = cuerpo + self.checksum
+            return
         m = modem()
         campos = bytes([self.version]) + bytes(self.mac_origen) + bytes(self.mac_destino) + \
             bytes([self.tipo, self.length, 0])
