@@ -208,3 +208,43 @@ def test_wav_and_capa1(cs, golden, tmp_path):
     for b, f, back in golden["capa1_byte_roundtrip"][::9]:
         x = mo.tone(capa1.byte_to_freq(b), 2205, 0.05, mo.scheme_a())
         assert capa1.detectar_frecuencia(x, 44100) == f and capa1.freq_to_byte(f) == back
+
+
+def test_capa1_main_plays_what_the_reference_played(golden, tmp_path, monkeypatch, capsys):
+    """Configuration 1, prototype scheme: capa1.main on the reference's sample file plays the ping
+    frame, the file's two frames and the literal example frame (golden: the frames the reference
+    played and their sample count); the audio equals the oracle's within float32 rounding, and
+    detecting every 2205-sample window of it gives exactly the oracle's freq_to_byte sequence
+    (bytes above 127 dropped, each 900 Hz end tone read as byte 20)."""
+    from scipy.io import wavfile
+
+    from wavenet_amd import capa1
+    g = golden["capa1_main_audio"]
+    src = tmp_path / "prueba.txt"
+    src.write_bytes(bytes.fromhex(golden["prueba_txt"]))
+    monkeypatch.chdir(tmp_path)
+    capa1.audio_reproducido()
+    capa1.main(["-a", str(src), "-b", "aa:bb:cc:dd:ee:ff", "-c", "11:22:33:44:55:66"])
+    audio = capa1.audio_reproducido()
+    assert audio.numel() == g["n_samples"]
+    sa = mo.scheme_a()
+    frames = [bytes.fromhex(f) for f in g["frames"]]
+    want = np.concatenate([np.concatenate([mo.tone(f, n, d, sa) for f, n, d in mo.schedule(fr, sa)]) for fr in frames])
+    assert np.max(np.abs(audio.cpu().numpy().astype(np.float64) - want)) <= 3e-8 + 5e-11
+    out = capsys.readouterr().out
+    assert out.count("Trama transmitida.") == 4 and "Enviando trama de 126 bytes..." in out
+    # decode: the oracle's detector and freq_to_byte on every aligned window of the float32 audio
+    bins, _ = mo.window_bins(audio.cpu().numpy().astype(np.float64), 2205)
+    freqs = np.abs(np.fft.fftfreq(2205, 1 / 44100))[bins]
+    oracle_bytes = [mo.freq_to_byte(float(f), sa) for f in freqs]
+    heard = capa1.decodificar_audio(audio)
+    assert heard == bytes(b for b in oracle_bytes if b is not None)
+    assert heard == b"".join(bytes(b for b in fr if b <= 127) + bytes([20]) for fr in frames)
+    rate, data = wavfile.read(str(tmp_path / "trama_128bytes_por_byte.wav"))
+    ga = golden["wav_a"]
+    assert rate == 44100 and len(data) == ga["n"] and data[:32].tolist() == ga["head"] and data[-32:].tolist() == ga["tail"]
+    # one tone alone
+    capa1.audio_reproducido()
+    tone = capa1.transmite_freq(900)
+    assert np.max(np.abs(tone.cpu().numpy() - mo.tone(900, 2205, 0.05, sa))) <= 3e-8 + 5e-11
+    assert torch.equal(capa1.audio_reproducido(), tone)

@@ -97,3 +97,24 @@ def test_one_hour_noisy_capture(mb):
     assert all(len(x) == 0 for x in got if len(x) != 126)      # the calls after the last frame time out empty
     rec = out["rec"].cpu().numpy().reshape(-1, 8).view(M.REC_DTYPE).reshape(-1)[:k]
     assert (rec["crc_ok"][[len(x) == 126 for x in got]] == 1).all()
+    # positions: over the first 1500 windows (three frames) the class word of every window and the
+    # (start window, end window, bytes, reason) of every listen call are the CPU oracle's on the same samples
+    from oracle import modem_oracle as mo
+    head = 1500
+    sch = mo.scheme_b()
+    bins, _ = mo.window_bins(audio[:head * WIN].cpu().numpy().astype(np.float64), WIN)
+    cls_o = mo.bin_classes(WIN, sch)[bins]
+    assert np.array_equal(out["cls"][0, :head].cpu().numpy().astype(np.uint16), cls_o)
+    assert np.array_equal(out["bin"][0, :head].cpu().numpy(), bins)
+    calls_o = [c for c in mo.slice_classes(cls_o, mo.timeout_to_windows(123.0, sch), nf + 4) if c[1] < head - 1]
+    assert len(calls_o) >= 3
+    for j, (w0, w1, b, r) in enumerate(calls_o):
+        assert (int(out["start"][0, j]), int(out["end"][0, j]), got[j], int(out["reason"][0, j])) == (w0, w1, b, r)
+    # and every later frame sits where its samples were put: a call ends within two windows of the
+    # end of the frame's EOF tone (the EOF tone is 3 windows long, a call ends at the first EOF-class one)
+    ends = out["end"][0, :k].cpu().numpy()
+    starts = out["start"][0, :k].cpu().numpy()
+    assert (starts[1:] == ends[:-1]).all() and starts[0] == 0
+    frame_end = ((dst + ns).numpy() + WIN - 1) // WIN
+    whole_idx = [j for j, x in enumerate(got) if len(x) == 126]
+    assert all(0 <= frame_end[i] - ends[j] <= 3 for i, j in enumerate(whole_idx))
