@@ -106,6 +106,87 @@ def cpu_baseline_all_cores(n_streams):
     return audio_s / max(dt for _, dt in res), cores, wall
 
 
+def profile_traffic(kernel, units, units_key, suffix="_pmc.json"):
+    """(HBM bytes per launch, source text) of `kernel` from the newest committed counter summary
+    under profiles/ (by modification time), scaled from the units per launch recorded there to
+    `units`; (None, reason) when there is no summary, it lacks the kernel, or it does not record
+    its launch size."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), key=os.path.getmtime)
+    files = [f for f in files if suffix != "_pmc.json" or not f.endswith("_kernelbench_pmc.json")]
+    if not files:
+        return None, "no committed counter summary under profiles/"
+    path = files[-1]
+    with open(path) as f:
+        pmc = json.load(f)
+    k = pmc.get("kernels", {}).get(kernel, {})
+    base = pmc.get(units_key)
+    if "hbm_bytes" not in k or not base:
+        return None, "profiles/%s has no per-launch bytes of %s" % (os.path.basename(path), kernel)
+    return k["hbm_bytes"] * units / base, (
+        "from committed profile profiles/%s (rocprofv3 --pmc FETCH_SIZE, x2 for 16-byte streaming reads on gfx950, + "
+        "WRITE_SIZE passes of this command at commit %s), scaled by launch size %s/%s; not measured by this run"
+        % (os.path.basename(path), pmc.get("source_commit_or_parent", "?"), units, base))
+
+
+def timed_launches(fn, reps=3):
+    """Mean milliseconds of `fn` over `reps` launches, by events on the stream it launches on."""
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def kernelbench_traffic(kernel):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernelbench_pmc.json")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        k = json.load(f).get("kernels", {}).get(kernel, {})
+    return k.get("hbm_bytes"), "profiles/" + os.path.basename(files[-1])
+
+
+def side_measurements(m, audio, n_streams, stride, nwin):
+    """Outside the timed steps: the two HBM-bound kernels that are not on the round trip's critical
+    path, each timed live over its full-size workload.  `sync`: the ping search over the audio of
+    the last step.  `crc`: parse + validate of 10 M frames at stride 128, payload 0..107, 1 % corrupted.
+    `traffic` is the counter figure of the same launch size from tools/kernel_bench.py's committed passes."""
+    out = {}
+    ms = timed_launches(lambda: m.sync_scan(audio, n_streams, stride, nwin))
+    by = n_streams * nwin * (WIN * 4 + 9)
+    tr, src = kernelbench_traffic("sync_kernel<7055>")
+    out["sync"] = {"bound": "hbm", "kernel": "sync_kernel<7055>", "ms_per_launch": ms, "algorithmic_bytes": by,
+                   "achieved_GBps": by / ms / 1e6, "peak_GBps": 8000.0, "frac": by / ms / 1e6 / 8000.0,
+                   "traffic": tr if n_streams * nwin == 4330000 else None, "traffic_source": src}
+    n = 10_000_000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rows = torch.randint(0, 256, (n, 128), dtype=torch.uint8, device="cuda", generator=g)
+    plen = torch.randint(0, 108, (n,), dtype=torch.int32, device="cuda", generator=g)
+    rows[:, 14] = plen.to(torch.uint8)
+    nbytes = plen + 19
+    crc = m.crc32(rows, plen + 15)
+    ar = torch.arange(n, device="cuda")
+    idx = (15 + plen).to(torch.int64)
+    for k in range(4):
+        rows[ar, idx + k] = ((crc >> (8 * (3 - k))) & 0xFF).to(torch.uint8)
+    bad = torch.rand(n, device="cuda", generator=g) < 0.01
+    pos = (torch.rand(n, device="cuda", generator=g) * nbytes).to(torch.int64)
+    rows[ar[bad], pos[bad]] ^= 0x10
+    r = m.parse_frames(rows, nbytes).cpu().numpy().view(M.REC_DTYPE).reshape(-1)
+    assert np.array_equal((r["status"] != 0) | (r["crc_ok"] == 0), bad.cpu().numpy()), "exactly the corrupted frames fail"
+    ms = timed_launches(lambda: m.parse_frames(rows, nbytes))
+    by = int(nbytes.sum().item()) + 12 * n
+    tr, src = kernelbench_traffic("crc_rows_kernel<1, 8>")
+    out["crc"] = {"bound": "hbm", "kernel": "crc_rows_kernel<parse+validate>", "ms_per_launch": ms, "frames": n,
+                  "algorithmic_bytes": by, "achieved_GBps": by / ms / 1e6, "peak_GBps": 8000.0,
+                  "frac": by / ms / 1e6 / 8000.0, "frames_per_s": n / ms * 1e3, "traffic": tr, "traffic_source": src}
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="ranks = devices of this node to use")
@@ -119,6 +200,8 @@ def parse_args(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="ranks may share a device (rank r uses device r mod device count): rehearsal of the "
                          "multi-rank branch on a box with fewer devices than ranks; needs --backend gloo")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements after the timed steps (sync search, checksum batch)")
     ap.add_argument("--rank-info", action="store_true",
                     help="each rank prints its rank environment as one JSON line and exits (no GPU work)")
     return ap.parse_args(argv)
@@ -290,15 +373,13 @@ def main():
         win_per_launch = sub * nwin
         flop = detect_flop_per_window(n1, n2) * win_per_launch
         achieved = flop / (det_ms * 1e-3) / 1e12
-        # HBM traffic of the detection launch from the committed PMC passes of this same command
-        traffic = None
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-        pmc_path = pmc_files[-1] if pmc_files else ""
-        if pmc_path:
-            with open(pmc_path) as f:
-                pmc = json.load(f)["kernels"].get("detect_kernel<83, 85, false>", {})
-            if "hbm_bytes" in pmc:
-                traffic = pmc["hbm_bytes"] * win_per_launch / 4330000.0
+        # HBM traffic of a detection launch: not measurable from inside this process; taken from the
+        # newest committed counter passes of this same command, only if they are of this kernel and
+        # scaled by the windows per launch stored with them
+        traffic, traffic_source = profile_traffic("detect_kernel<83, 85, false>", win_per_launch, "windows_per_launch")
+        extras = {}
+        if not args.no_extras and world == 1:
+            extras = side_measurements(m, audio, sub, stride, nwin)
         line = {
             "metric": "audio-seconds demodulated/sec", "value": value, "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -318,13 +399,16 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "detect_kernel<83,85> (+ float64 re-evaluation pass)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + "
-                                           "WRITE_SIZE passes of this command, bytes per launch" % os.path.basename(pmc_path),
+                         "traffic_source": traffic_source,
                          "flop_per_window": detect_flop_per_window(n1, n2), "windows_per_launch": win_per_launch,
                          "ms_per_launch": det_ms},
-            "synth": {"bound": "hbm", "ms_per_launch": syn_ms,
-                      "achieved_GBps": sub * stride * 4 / (syn_ms * 1e-3) / 1e9, "peak_GBps": 8000.0},
+            "synth": {"bound": "hbm", "kernel": "synth_kernel<float>", "ms_per_launch": syn_ms,
+                      "algorithmic_bytes": sub * stride * 4,
+                      "achieved_GBps": sub * stride * 4 / (syn_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                      "frac": sub * stride * 4 / (syn_ms * 1e-3) / 1e9 / 8000.0,
+                      "traffic": profile_traffic("synth_kernel<float>", sub * stride, "samples_per_launch")[0]},
         }
+        line.update(extras)
         if args.cpu_streams > 0 and world == 1:
             v, dt = cpu_baseline(args.cpu_streams)
             line["cpu_baseline"] = {"value": v, "unit": "audio-s/s", "cores": 1, "kind": "port",

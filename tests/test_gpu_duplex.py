@@ -181,10 +181,16 @@ def test_layer2_packet_text_survives_the_sound_link(duplex):
     Packet.form (WaveNetPacketeering.py:36-49), not produced by running the reference."""
     from wavenet_amd.dispositivo_wavenet.dispositivo_wavenet import DispositivoWaveNet
 
+    from paquete_l2 import Paquete, es_nulo, forma, reconstruir
+
     a, b = "0:0:0:0:0:0", "1:1:1:1:1:1"
-    campos = {"enc": False, "src": 1, "dest": 2, "mtype": "msg", "body": "ahu, ahua", "timestamp": "nope"}
-    texto = json.dumps(campos)
+    paquete = Paquete(1, 2, "msg", "ahu, ahua", "nope")
+    texto = forma(paquete)
     out = run_endpoints({"tx": lambda: DispositivoWaveNet(a, b).send(texto, timeout=60 * 3),
                          "rx": lambda: DispositivoWaveNet(b, "").listen(timeout=60 * 3, init_timeout=40)})
     assert out["rx"]["result"] == texto
-    assert json.loads(out["rx"]["result"]) == campos
+    # what SoundProtocol.listener does next (WaveNetProtocols.py:326): reconstruct_packet(data)
+    recibido = reconstruir(out["rx"]["result"])
+    assert recibido == paquete and not es_nulo(recibido)
+    # a text damaged on the way (here: cut short) reconstructs to the null packet instead of raising
+    assert es_nulo(reconstruir(out["rx"]["result"][:-9]))
