@@ -185,6 +185,29 @@ __device__ __forceinline__ float dpp_f0(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xF, false));
 }
 
+// Sum / maximum over the wave, valid in lane 63 (same DPP steps as the top-three merge: pairs,
+// quads, eights, sixteens inside each row, then the rows collected in the last one).
+__device__ __forceinline__ float wave_sum63(float v) {
+    v += dpp_f0<0xB1, 0xF>(v);
+    v += dpp_f0<0x4E, 0xF>(v);
+    v += dpp_f0<0x141, 0xF>(v);
+    v += dpp_f0<0x140, 0xF>(v);
+    v += dpp_f0<0x142, 0xA>(v);
+    v += dpp_f0<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max63(unsigned v) {
+    v = max(v, dpp_u<0xB1, 0xF>(v));
+    v = max(v, dpp_u<0x4E, 0xF>(v));
+    v = max(v, dpp_u<0x141, 0xF>(v));
+    v = max(v, dpp_u<0x140, 0xF>(v));
+    v = max(v, dpp_u<0x142, 0xA>(v));
+    v = max(v, dpp_u<0x143, 0xC>(v));
+    return v;
+}
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ unsigned lane63(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
+
 template <int N1, int N2, bool PROF>
 __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict__ audio, long long n_streams,
                                                         long long stream_stride, long long first_sample,
@@ -193,7 +216,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                                                         const uint16_t *__restrict__ lut, float keep,
                                                         float err_lin, float err_sq,
                                                         uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
-                                                        int32_t *__restrict__ out_bin) {
+                                                        int32_t *__restrict__ out_bin,
+                                                        unsigned long long *__restrict__ stats) {
     typedef Plan<N1, N2> P;
     constexpr int N = P::N, TA = P::TA, T1 = P::T1, C2T = P::C2T, KS1 = P::KS1, KS2 = P::KS2;
     constexpr int H1 = P::H1, H2 = P::H2;
@@ -275,6 +299,21 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         cb_p[t] = 4 * ((N2 * a + N1 * (KS1 * lg)) % N);
         cb_m[t] = 4 * ((N2 * a + N * N1 - N1 * (KS1 - 1 + KS1 * lg)) % N);
     }
+    // Energy of the window from the folded samples of stage 1: the four A-operand values of a
+    // lane (sums and differences over a mirrored column pair and a mirrored row pair) are an
+    // orthogonal transform of four samples scaled by 2, so their squares sum to 4 * (sum of the
+    // four samples' squares).  Weights undo what is read twice or is padding: row a' = 0 is its
+    // own mirror (1/2), rows a' > h1 repeat other rows (0); column b' = 0 is its own mirror
+    // (1/2, first k-step, lane group 0), column b' > h2 is padding (0, last k-step).
+    float w_row[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        const int ap = 16 * t + 4 * (li & 3) + (li >> 2);
+        w_row[t] = ap > H1 ? 0.f : (ap == 0 ? 0.5f : 1.f);
+    }
+    const float w_first = lg == 0 ? 0.5f : 1.f;
+    const float w_last = (KS1 - 1 + KS1 * lg) > H2 ? 0.f : 1.f;
+    unsigned long long cols_done = 0;   // columns k2 whose second stage this wave ran (statistics)
     __syncthreads();
 
     // bins of this lane's outputs (tile, register, column tile, plus/minus side), kept in
@@ -388,17 +427,30 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 raw_m[t % TA][t / TA] = *(const float *)(smem + ad_m[t] + 4 * N1 * (KS1 - 1 - ks));
             });
         };
-        auto fold = [&]() {        // samples read last -> A operands: fold columns, then rows
+        floatx2 e4[TA];            // running sums of the squared A operands, per row-tile pair
+        auto fold = [&](auto KS) {   // samples read last -> A operands of k-step KS: fold columns, then rows
+            constexpr int ks = decltype(KS)::value;
             static_for<TA>([&](auto T) {
                 constexpr int t = decltype(T)::value;
                 const floatx2 sab = raw_p[t] + raw_m[t], dab = raw_p[t] - raw_m[t];   // (sa, sb), (da, db)
                 xs[t] = pk_butterfly(sab);                                            // (sa + sb, sa - sb)
                 xd[t] = pk_butterfly(dab);
+                if constexpr (ks == 0) {
+                    e4[t] = (xs[t] * xs[t] + xd[t] * xd[t]) * w_first;
+                } else if constexpr (ks == KS1 - 1) {
+                    e4[t] += (xs[t] * xs[t] + xd[t] * xd[t]) * w_last;
+                } else {
+                    e4[t] += xs[t] * xs[t];
+                    e4[t] += xd[t] * xd[t];
+                }
+                // keeps the sums here, between the matrix instructions of two k-steps (left to
+                // itself the compiler holds every k-step's operands and squares them after stage 1)
+                asm volatile("" : "+v"(e4[t]));
             });
         };
         rd(ic<0>{});
         __builtin_amdgcn_sched_barrier(0);
-        fold();
+        fold(ic<0>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (KS1 > 1) rd(ic<1>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -418,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             });
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (ks + 1 < KS1) {
-                fold();                                    // operands of k-step ks+1 (read before this k-step's MFMAs)
+                fold(ic<ks + 1>{});                        // operands of k-step ks+1 (read before this k-step's MFMAs)
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ks + 2 < KS1)
                     rd(ic<ks + 2>{});
@@ -438,47 +490,95 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         lap(ic<2>{});
         mfma_drain();
 
+        // ------------------------------------------------------------------ between the stages
+        // Energy of the half spectrum the reference searches, E = sum_{k <= N/2} |X_k|^2
+        // = (N * sum x^2 + X_0^2) / 2 (N odd), from the samples: an upper bound for every bin and
+        // the scale of the float32 error.  X_0 = sum x is the sum of column k2 = 0 of the stage-1
+        // results (lanes with li = 0, sum tiles, rows a' <= h1, the self-mirrored row halved).
+        // Rough energy of each column tile of stage 1 (four rows of it): the order in which
+        // stage 2 takes the column tiles.
+        float e4l = 0.f;
+#pragma unroll
+        for (int t = 0; t < TA; ++t) e4l = fmaf(e4[t].x + e4[t].y, w_row[t], e4l);
+        float x0l = 0.f;
+        static_for<TA>([&](auto T) {
+            static_for<4>([&](auto R) {
+                constexpr int t = decltype(T)::value, r = decltype(R)::value, a0 = 16 * t + 4 * r;
+                if constexpr (a0 <= H1) {
+                    float v = Yr[0][t][r];
+                    if constexpr (a0 + 3 > H1) v = (a0 + lg <= H1) ? v : 0.f;
+                    if constexpr (a0 == 0) v = lg == 0 ? 0.5f * v : v;
+                    x0l += v;
+                }
+            });
+        });
+        x0l = li == 0 ? x0l : 0.f;
+        float ec[C2T];
+#pragma unroll
+        for (int c = 0; c < C2T; ++c)
+            ec[c] = Yr[c][0][0] * Yr[c][0][0] + Yi[c][0][0] * Yi[c][0][0] + Yr[c][TA][0] * Yr[c][TA][0] +
+                    Yi[c][TA][0] * Yi[c][TA][0];
+        const float sx2 = 0.25f * lane63(wave_sum63(e4l)), x0 = lane63(wave_sum63(x0l));
+        const float e_half = 0.5f * fmaf((float)N, sx2, x0 * x0) * (1.f + 1e-5f);   // wave-uniform from here on
+        unsigned eo[C2T];
+#pragma unroll
+        for (int c = 0; c < C2T; ++c) eo[c] = lane63(__float_as_uint(wave_sum63(ec[c])));   // non-negative floats order like their bits
+        // column tiles in descending rough energy (NaN patterns sort somewhere: any order is valid)
+        int ord[3] = {0, 1, 2};
+        if constexpr (C2T == 2) {
+            if (eo[1] > eo[0]) { ord[0] = 1; ord[1] = 0; }
+        } else {
+            unsigned k0 = eo[0], k1v = eo[1], k2v = eo[C2T - 1];
+            if (k1v > k0) { unsigned tk = k0; k0 = k1v; k1v = tk; int ti = ord[0]; ord[0] = ord[1]; ord[1] = ti; }
+            if (k2v > k0) { unsigned tk = k0; k0 = k2v; k2v = tk; int ti = ord[0]; ord[0] = ord[2]; ord[2] = ti; }
+            if (k2v > k1v) { int ti = ord[1]; ord[1] = ord[2]; ord[2] = ti; }
+        }
+
         // ------------------------------------------------------------------ stage 2
         Top3 best;
         best.k1 = best.k2 = best.k3 = 0u;
         best.mx = 0u;
-        floatx2 esum = {0.f, 0.f};   // sum of |Z|^2 over this lane's outputs (the excluded bin included)
-        static_for<TA>([&](auto TT) {
-            constexpr int tt = decltype(TT)::value;
-            floatx4 acc[4][C2T];   // the sums A, B, C, E
+        float eproc = 0.f;   // energy of the outputs this lane has looked at (each bin once)
+        auto col_tile = [&](auto C) {   // every output with k2 in column tile C
+            constexpr int c = decltype(C)::value;
+            floatx4 acc[TA][4];   // the sums A, B, C, E of each row tile
             static_for<KS2>([&](auto S) {
                 constexpr int s = decltype(S)::value, tau = s >> 2, r = s & 3;
-                static_for<C2T>([&](auto C) {
-                    constexpr int c = decltype(C)::value;
+                static_for<TA>([&](auto TT) {
+                    constexpr int tt = decltype(TT)::value;
                     if constexpr (s == 0) {
-                        mfma2_new(acc[0][c], t1c[tt][s], Yr[c][tau][r]);
-                        mfma2_new(acc[2][c], t1c[tt][s], Yi[c][tau][r]);
-                        mfma2_new(acc[1][c], t1s[tt][s], Yi[c][tau + TA][r]);
-                        mfma2_new(acc[3][c], t1s[tt][s], Yr[c][tau + TA][r]);
+                        mfma2_new(acc[tt][0], t1c[tt][s], Yr[c][tau][r]);
+                        mfma2_new(acc[tt][2], t1c[tt][s], Yi[c][tau][r]);
+                        mfma2_new(acc[tt][1], t1s[tt][s], Yi[c][tau + TA][r]);
+                        mfma2_new(acc[tt][3], t1s[tt][s], Yr[c][tau + TA][r]);
                     } else {
-                        mfma2_acc(acc[0][c], t1c[tt][s], Yr[c][tau][r]);
-                        mfma2_acc(acc[2][c], t1c[tt][s], Yi[c][tau][r]);
-                        mfma2_acc(acc[1][c], t1s[tt][s], Yi[c][tau + TA][r]);
-                        mfma2_acc(acc[3][c], t1s[tt][s], Yr[c][tau + TA][r]);
+                        mfma2_acc(acc[tt][0], t1c[tt][s], Yr[c][tau][r]);
+                        mfma2_acc(acc[tt][2], t1c[tt][s], Yi[c][tau][r]);
+                        mfma2_acc(acc[tt][1], t1s[tt][s], Yi[c][tau + TA][r]);
+                        mfma2_acc(acc[tt][3], t1s[tt][s], Yr[c][tau + TA][r]);
                     }
                 });
             });
             mfma_drain();
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int tt = 0; tt < TA; ++tt)
 #pragma unroll
-                for (int c = 0; c < C2T; ++c) after_drain(acc[i][c]);
+                for (int i = 0; i < 4; ++i) after_drain(acc[tt][i]);
             __builtin_amdgcn_sched_barrier(0);
-            // arg-max work of the tile: two outputs per accumulator element; the float part on
-            // register pairs (packed f32 instructions), the keys one by one
-            static_for<2>([&](auto HALF) {
-                static_for<C2T>([&](auto C) {
-                    constexpr int hf = decltype(HALF)::value, c = decltype(C)::value;
-                    const floatx2 A = hf ? acc[0][c].hi : acc[0][c].lo, B = hf ? acc[1][c].hi : acc[1][c].lo;
-                    const floatx2 Cc = hf ? acc[2][c].hi : acc[2][c].lo, E = hf ? acc[3][c].hi : acc[3][c].lo;
+            // arg-max work of the column tile: two outputs per accumulator element; the float part
+            // on register pairs (packed f32 instructions), the keys one by one
+            floatx2 es_p = {0.f, 0.f}, es_m = {0.f, 0.f};
+            float dup_row0 = 0.f;
+            static_for<TA>([&](auto TT) {
+                static_for<2>([&](auto HALF) {
+                    constexpr int tt = decltype(TT)::value, hf = decltype(HALF)::value;
+                    const floatx2 A = hf ? acc[tt][0].hi : acc[tt][0].lo, B = hf ? acc[tt][1].hi : acc[tt][1].lo;
+                    const floatx2 Cc = hf ? acc[tt][2].hi : acc[tt][2].lo, E = hf ? acc[tt][3].hi : acc[tt][3].lo;
                     const floatx2 rp = A + B, rm = A - B, ip = Cc - E, im = Cc + E;
                     const floatx2 mp2 = rp * rp + ip * ip, mm2 = rm * rm + im * im;
-                    esum += mp2 + mm2;
+                    es_p += mp2;
+                    es_m += mm2;
+                    if constexpr (tt == 0 && hf == 0) dup_row0 = mm2.x;
                     static_for<2>([&](auto EL) {
                         constexpr int r = 2 * hf + decltype(EL)::value;
                         float mp = mp2[decltype(EL)::value], mm = mm2[decltype(EL)::value];
@@ -494,25 +594,53 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     });
                 });
             });
-        });
+            // each bin once: where k2 = 0 (column tile 0, li = 0) every minus-side output repeats its
+            // plus side, and so does the one of row k1 = 0 (row tile 0, register 0, lane group 0)
+            float em = es_m.x + es_m.y;
+            if constexpr (c == 0) em = li == 0 ? 0.f : em - (lg == 0 ? dup_row0 : 0.f);
+            else em -= lg == 0 ? dup_row0 : 0.f;
+            eproc += (es_p.x + es_p.y) + em;
+        };
+        // Column tiles still to do cannot matter once everything outside the outputs already
+        // seen holds less energy than the smallest value that could still change the decision
+        // (`lim`, below).  The float32 energy of the outputs seen can exceed the exact one by
+        // 2B*sum|Z| + n*B^2 <= 2B*sqrt(n*E) < 0.005 E (B = 724u*sqrt(E), n < 3600 outputs).
+        auto rest_cannot_matter = [&]() {
+            const float f1u = __uint_as_float(lane63(wave_max63(best.mx)));
+            const float seen = lane63(wave_sum63(eproc));
+            const float lim_now = (f1u * (1.f - 1.f / 2048.f) - (err_lin * (sqrtf(f1u) * sqrtf(e_half)) + err_sq * e_half)) * keep;
+            return e_half * 1.005f - seen * (1.f - 1e-5f) < lim_now;
+        };
+        constexpr int NCOL[3] = {16, C2T > 2 ? 16 : P::K2 - 16, P::K2 - 16 * (C2T - 1)};
+#pragma nounroll
+        for (int i = 0; i < C2T; ++i) {
+            const int c = i == 0 ? ord[0] : (i == 1 ? ord[1] : ord[2]);
+            if (c == 0) {
+                col_tile(ic<0>{});
+                cols_done += 16;
+            } else if (c == 1) {
+                col_tile(ic<1>{});
+                cols_done += NCOL[1];
+            } else {
+                if constexpr (C2T > 2) col_tile(ic<2>{});
+                cols_done += NCOL[2];
+            }
+            if (i + 1 < C2T && rest_cannot_matter()) break;
+        }
         lap(ic<3>{});
         // wave-wide merge of the per-lane top three, all by DPP: lane pairs, quads, eights and
         // sixteens merge two disjoint lane sets each and leave every lane of a row with the
         // row's result; two row broadcasts then collect the four rows in the last row (the
         // other rows merge with themselves and are not used).  Lane 63 decides and stores.
-        float etot = esum.x + esum.y;
-        auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, unsigned om, float oe) {
+        auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, unsigned om) {
             best.mx = max(best.mx, om);
             top3_insert(best, o1);
             top3_insert(best, o2);
             top3_insert(best, o3);
-            etot += oe;
         };
-        // the energy of the other lane set rides along; in the two broadcast steps a row that is not
-        // written keeps its own partial sum, and lane 63 ends with the sum over the wave
 #define WN_MERGE_DPP(CTRL, ROWS)                                                                        \
     merge_with(dpp_u<CTRL, ROWS>(best.k1), dpp_u<CTRL, ROWS>(best.k2), dpp_u<CTRL, ROWS>(best.k3),     \
-               dpp_u<CTRL, ROWS>(best.mx), dpp_f0<CTRL, ROWS>(etot))
+               dpp_u<CTRL, ROWS>(best.mx))
         WN_MERGE_DPP(0xB1, 0xF);    // quad_perm [1,0,3,2]
         WN_MERGE_DPP(0x4E, 0xF);    // quad_perm [2,3,0,1]
         WN_MERGE_DPP(0x141, 0xF);   // row_half_mirror
@@ -521,23 +649,24 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         WN_MERGE_DPP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
 #undef WN_MERGE_DPP
         {
-            // A largest |Z|^2 below 1e-30 or a total energy above 1e30 (zero, or samples so small or
+            // A largest |Z|^2 below 1e-30 or an energy above 1e30 (zero, or samples so small or
             // so large that float32 squares lose their meaning, or not a number) is not decided
             // here: the window goes to the float64 pass, which also recognises all-zero windows.
             const float mxf = __uint_as_float(best.mx);
-            const bool odd = !(mxf >= 1e-30f && etot <= 1e30f);
+            const bool odd = !(mxf >= 1e-30f && e_half <= 1e30f);
             // Keys carry |Z|^2 truncated to 2^-11 relative.  The float32 value of every |Z|^2 is
-            // within err_lin*sqrt(|Z|^2 * E) + err_sq*E of the exact one (E = energy of the whole
-            // spectrum, of which etot is an upper bound up to rounding; derivation at launch_detect),
-            // so a bin whose key value, rounded up, reaches `lim` may be the true maximum.
+            // within err_lin*sqrt(|Z|^2 * E) + err_sq*E of the exact one (E = energy of the half
+            // spectrum; derivation at launch_detect), so a bin whose key value, rounded up, reaches
+            // `lim` may be the true maximum.  Outputs of column tiles that were left out are all
+            // below it.
             const float f1 = __uint_as_float(best.k1 & ~KEY_BIN), f2 = __uint_as_float(best.k2 & ~KEY_BIN),
                         f3 = __uint_as_float(best.k3 & ~KEY_BIN);
-            const float lim = (f1 - (err_lin * (sqrtf(mxf) * sqrtf(etot)) + err_sq * etot)) * keep;
+            const float lim = (f1 - (err_lin * (sqrtf(mxf) * sqrtf(e_half)) + err_sq * e_half)) * keep;
             // The magnitude that is reported must hold to 1e-4 relative as well.  Its float32 error
             // is a few 1e-9 * sqrt(E) in practice (measured; the bound above is the worst case), so
             // a searched maximum holding less than 1e-6 of the energy (nearly everything sits in the
             // one bin that is not searched) is recomputed in float64 too.
-            const bool faint = etot > 1e6f * mxf;
+            const bool faint = e_half > 1e6f * mxf;
             const bool full = odd | faint | (f3 >= lim), top2 = f2 >= lim;
             const int b = (int)(best.k1 & KEY_BIN);
             const unsigned cls = lut_s[odd ? 0 : b];
@@ -551,6 +680,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         w = wn;
     }
     flush();
+    if (lane == 0 && cols_done) atomicAdd(&stats[3], cols_done);
     if constexpr (PROF) {
         // out_bin[0..4]: clocks/256 per phase (DMA wait, stage 1, stores + next DMA issue,
         // stage 2 with its arg-max work, merge + decision); [7]: total clocks/256;
@@ -688,7 +818,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
 template <int N1, int N2>
 static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
                          int64_t stream_stride, int64_t first_sample, int64_t n_windows, uint16_t *d_cls,
-                         float *d_mag, int32_t *d_bin, hipStream_t st) {
+                         float *d_mag, int32_t *d_bin, unsigned long long *stats, hipStream_t st) {
     typedef Plan<N1, N2> P;
     // ctx->detect_profile (WN_DETECT_PROFILE=1 when the context was made; diagnostics, results
     // are not usable): per-phase clock counts of wave 0 in out_bin[0..8]
@@ -722,12 +852,12 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
         hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq,
-                           d_cls, d_mag, d_bin);
+                           d_cls, d_mag, d_bin, stats);
     else
         hipLaunchKernelGGL((detect_kernel<N1, N2, false>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq,
-                           d_cls, d_mag, d_bin);
+                           d_cls, d_mag, d_bin, stats);
     return wn_launch_check("detect_kernel");
 }
 
@@ -781,10 +911,10 @@ static int detect_run(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int6
     int rc;
     if (ctx->n1 == 83 && ctx->n2 == 85)
         rc = launch_detect<83, 85>(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls,
-                                   d_mag, d_bin, st);
+                                   d_mag, d_bin, stats, st);
     else if (ctx->n1 == 45 && ctx->n2 == 49)
         rc = launch_detect<45, 49>(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls,
-                                   d_mag, d_bin, st);
+                                   d_mag, d_bin, stats, st);
     else {
         wn_set_error("no detection kernel for %d x %d", ctx->n1, ctx->n2);
         return WN_ERR_UNSUPPORTED;
