@@ -1,4 +1,5 @@
-"""Per-phase shader-clock counts of the detection kernel's window loop (wave 0 of workgroup 0).
+"""Per-phase shader-clock counts of the detection kernel's window loop (wave 0 of workgroup 0),
+on noise (no column tile of stage 2 can be left out) and on clean frames (most can).
 
 Run with WN_DETECT_PROFILE=1 in the environment: the library then launches the instrumented
 build of the kernel, which leaves the counts in the first entries of the bin output.
@@ -16,14 +17,24 @@ m = M.Modem(M.esquema_b())
 S = 2000
 stride = M.pad4(m.esquema.max_frame_samples(126))
 nwin = stride // 7055
-audio = 0.3 * torch.randn((S, stride), device="cuda")
-for i in range(3):
-    cls, mag, kbin = m.detect(audio, S, stride, nwin)
-torch.cuda.synchronize()
-v = kbin.view(-1)[:9].tolist()
-nw = (S * nwin + 1023) // 1024
-names = ["dma wait", "stage 1", "stores + next dma", "stage 2 + arg-max", "merge + decision"]
-for n, c in zip(names, v):
-    print("%-20s %8.0f clocks/window" % (n, c * 256.0 / nw))
-print("%-20s %8.0f clocks/window" % ("total", v[7] * 256.0 / nw))
-print("shader clock %.3f GHz" % (v[7] / v[8] * 0.1))
+g = torch.Generator().manual_seed(1)
+fields = torch.zeros((S, 16), dtype=torch.uint8)
+fields[:, 0] = 1
+fields[:, 1:13] = torch.randint(0, 256, (S, 12), dtype=torch.uint8, generator=g)
+fields[:, 13] = 3
+fields[:, 14] = 107
+frames, lens = m.build_frames(fields.cuda(), torch.randint(0, 256, (S, 112), dtype=torch.uint8, generator=g).cuda(), 128)
+clean, _ = m.encode_streams(frames, lens, stride)
+names = ["dma wait", "stage 1", "stores + next dma", "stage 2 + arg-max", "merge + decision", "energies + order"]
+for what, audio in (("noise", 0.3 * torch.randn((S, stride), device="cuda")), ("clean frames", clean)):
+    for i in range(3):
+        m.detect_stats()
+        cls, mag, kbin = m.detect(audio, S, stride, nwin)
+    torch.cuda.synchronize()
+    v = kbin.view(-1)[:9].tolist()
+    nw = (S * nwin + 1023) // 1024
+    print(what)
+    for n, c in zip(names, v):
+        print("  %-20s %8.0f clocks/window" % (n, c * 256.0 / nw))
+    print("  %-20s %8.0f clocks/window" % ("total", v[7] * 256.0 / nw))
+    print("  shader clock %.3f GHz" % (v[7] / v[8] * 0.1))

@@ -207,6 +207,8 @@ __device__ __forceinline__ unsigned wave_max63(unsigned v) {
 }
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 __device__ __forceinline__ unsigned lane63(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
+template <class T>
+__device__ __forceinline__ float lane_f(float v, T lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 template <int N1, int N2, bool PROF>
 __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict__ audio, long long n_streams,
@@ -512,27 +514,17 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 }
             });
         });
-        x0l = li == 0 ? x0l : 0.f;
         float ec[C2T];
 #pragma unroll
         for (int c = 0; c < C2T; ++c)
             ec[c] = Yr[c][0][0] * Yr[c][0][0] + Yi[c][0][0] * Yi[c][0][0] + Yr[c][TA][0] * Yr[c][TA][0] +
                     Yi[c][TA][0] * Yi[c][TA][0];
-        const float sx2 = 0.25f * lane63(wave_sum63(e4l)), x0 = lane63(wave_sum63(x0l));
+        const float sx2 = 0.25f * lane63(wave_sum63(e4l));
+        // column k2 = 0 lives in the lanes with li = 0: lanes 0, 16, 32, 48
+        const float x0 = (lane_f(x0l, 0) + lane_f(x0l, 16)) + (lane_f(x0l, 32) + lane_f(x0l, 48));
         const float e_half = 0.5f * fmaf((float)N, sx2, x0 * x0) * (1.f + 1e-5f);   // wave-uniform from here on
-        unsigned eo[C2T];
-#pragma unroll
-        for (int c = 0; c < C2T; ++c) eo[c] = lane63(__float_as_uint(wave_sum63(ec[c])));   // non-negative floats order like their bits
-        // column tiles in descending rough energy (NaN patterns sort somewhere: any order is valid)
-        int ord[3] = {0, 1, 2};
-        if constexpr (C2T == 2) {
-            if (eo[1] > eo[0]) { ord[0] = 1; ord[1] = 0; }
-        } else {
-            unsigned k0 = eo[0], k1v = eo[1], k2v = eo[C2T - 1];
-            if (k1v > k0) { unsigned tk = k0; k0 = k1v; k1v = tk; int ti = ord[0]; ord[0] = ord[1]; ord[1] = ti; }
-            if (k2v > k0) { unsigned tk = k0; k0 = k2v; k2v = tk; int ti = ord[0]; ord[0] = ord[2]; ord[2] = ti; }
-            if (k2v > k1v) { int ti = ord[1]; ord[1] = ord[2]; ord[2] = ti; }
-        }
+        const float sqrt_e = __builtin_amdgcn_sqrtf(e_half);
+        lap(ic<5>{});
 
         // ------------------------------------------------------------------ stage 2
         Top3 best;
@@ -605,16 +597,32 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // seen holds less energy than the smallest value that could still change the decision
         // (`lim`, below).  The float32 energy of the outputs seen can exceed the exact one by
         // 2B*sum|Z| + n*B^2 <= 2B*sqrt(n*E) < 0.005 E (B = 724u*sqrt(E), n < 3600 outputs).
-        auto rest_cannot_matter = [&]() {
-            const float f1u = __uint_as_float(lane63(wave_max63(best.mx)));
+        auto rest_cannot_matter = [&](unsigned &mx_out) {
+            mx_out = lane63(wave_max63(best.mx));
+            const float f1u = __uint_as_float(mx_out);
             const float seen = lane63(wave_sum63(eproc));
-            const float lim_now = (f1u * (1.f - 1.f / 2048.f) - (err_lin * (sqrtf(f1u) * sqrtf(e_half)) + err_sq * e_half)) * keep;
+            const float lim_now = (f1u - (err_lin * (__builtin_amdgcn_sqrtf(f1u) * sqrt_e) + err_sq * e_half)) * keep;
             return e_half * 1.005f - seen * (1.f - 1e-5f) < lim_now;
         };
         constexpr int NCOL[3] = {16, C2T > 2 ? 16 : P::K2 - 16, P::K2 - 16 * (C2T - 1)};
+        // The column tile with the largest rough energy first (any order is valid; this one ends
+        // the loop soonest), chosen again among the rest each time the loop has to go on.
+        unsigned todo = (1u << C2T) - 1u;
+        unsigned mxu = 0u;
+        bool have_max = false;
 #pragma nounroll
         for (int i = 0; i < C2T; ++i) {
-            const int c = i == 0 ? ord[0] : (i == 1 ? ord[1] : ord[2]);
+            int c;
+            if (i == C2T - 1) {
+                c = __ffs((int)todo) - 1;
+            } else {
+                unsigned key = 0u;   // energy bits (non-negative floats order like their bits), tile number in the low bits
+#pragma unroll
+                for (int q = 0; q < C2T; ++q)
+                    key = max(key, ((todo >> q) & 1u) ? ((__float_as_uint(ec[q]) & ~7u) | 4u | (unsigned)q) : 0u);
+                c = (int)(lane63(wave_max63(key)) & 3u);
+            }
+            todo &= ~(1u << c);
             if (c == 0) {
                 col_tile(ic<0>{});
                 cols_done += 16;
@@ -625,56 +633,64 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 if constexpr (C2T > 2) col_tile(ic<2>{});
                 cols_done += NCOL[2];
             }
-            if (i + 1 < C2T && rest_cannot_matter()) break;
+            if (i + 1 < C2T && rest_cannot_matter(mxu)) {
+                have_max = true;
+                break;
+            }
         }
         lap(ic<3>{});
-        // wave-wide merge of the per-lane top three, all by DPP: lane pairs, quads, eights and
-        // sixteens merge two disjoint lane sets each and leave every lane of a row with the
-        // row's result; two row broadcasts then collect the four rows in the last row (the
-        // other rows merge with themselves and are not used).  Lane 63 decides and stores.
-        auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3, unsigned om) {
-            best.mx = max(best.mx, om);
-            top3_insert(best, o1);
-            top3_insert(best, o2);
-            top3_insert(best, o3);
-        };
-#define WN_MERGE_DPP(CTRL, ROWS)                                                                        \
-    merge_with(dpp_u<CTRL, ROWS>(best.k1), dpp_u<CTRL, ROWS>(best.k2), dpp_u<CTRL, ROWS>(best.k3),     \
-               dpp_u<CTRL, ROWS>(best.mx))
-        WN_MERGE_DPP(0xB1, 0xF);    // quad_perm [1,0,3,2]
-        WN_MERGE_DPP(0x4E, 0xF);    // quad_perm [2,3,0,1]
-        WN_MERGE_DPP(0x141, 0xF);   // row_half_mirror
-        WN_MERGE_DPP(0x140, 0xF);   // row_mirror
-        WN_MERGE_DPP(0x142, 0xA);   // row_bcast:15 into rows 1 and 3
-        WN_MERGE_DPP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
+        if (!have_max) mxu = lane63(wave_max63(best.mx));
+        // From here on `mxu`, and everything computed from it, is the same in every lane.
+        // A largest |Z|^2 below 1e-30 or an energy above 1e30 (zero, or samples so small or so
+        // large that float32 squares lose their meaning, or not a number) is not decided here: the
+        // window goes to the float64 pass, which also recognises all-zero windows.
+        const float mxf = __uint_as_float(mxu);
+        const bool odd = !(mxf >= 1e-30f && e_half <= 1e30f);
+        // Keys carry |Z|^2 truncated to 2^-11 relative.  The float32 value of every |Z|^2 is
+        // within err_lin*sqrt(|Z|^2 * E) + err_sq*E of the exact one (E = energy of the half
+        // spectrum; derivation at launch_detect), so a bin whose key value, rounded up, reaches
+        // `lim` may be the true maximum.  Outputs of column tiles that were left out are all below it.
+        const float lim = (mxf - (err_lin * (__builtin_amdgcn_sqrtf(mxf) * sqrt_e) + err_sq * e_half)) * keep;
+        // The magnitude that is reported must hold to 1e-4 relative as well.  Its float32 error is a
+        // few 1e-9 * sqrt(E) in practice (measured; the bound above is the worst case), so a searched
+        // maximum holding less than 1e-6 of the energy (nearly everything sits in the one bin that
+        // is not searched) is recomputed in float64 too.
+        const bool faint = e_half > 1e6f * mxf;
+        const unsigned long long in1 = __ballot(__uint_as_float(best.k1 & ~KEY_BIN) >= lim);
+        const unsigned long long in2 = __ballot(__uint_as_float(best.k2 & ~KEY_BIN) >= lim);
+        pend_mag = odd ? 0.f : __builtin_amdgcn_sqrtf(mxf);
+        pend_w = w;
+        pend = true;
+        if (!odd && !faint && in2 == 0ull && __popcll(in1) == 1) {
+            // the usual case: one output of one lane stands alone above the limit
+            const int b = (int)((unsigned)__builtin_amdgcn_readlane((int)best.k1, __ffsll((long long)in1) - 1) & KEY_BIN);
+            pend_bin = b;
+            pend_cls = lut_s[b];
+        } else {
+            // wave-wide merge of the per-lane top three, all by DPP: lane pairs, quads, eights and
+            // sixteens merge two disjoint lane sets each and leave every lane of a row with the
+            // row's result; two row broadcasts then collect the four rows in the last row (the
+            // other rows merge with themselves and are not used).  Lane 63 decides and stores.
+            auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3) {
+                top3_insert(best, o1);
+                top3_insert(best, o2);
+                top3_insert(best, o3);
+            };
+#define WN_MERGE_DPP(CTRL, ROWS) \
+    merge_with(dpp_u<CTRL, ROWS>(best.k1), dpp_u<CTRL, ROWS>(best.k2), dpp_u<CTRL, ROWS>(best.k3))
+            WN_MERGE_DPP(0xB1, 0xF);    // quad_perm [1,0,3,2]
+            WN_MERGE_DPP(0x4E, 0xF);    // quad_perm [2,3,0,1]
+            WN_MERGE_DPP(0x141, 0xF);   // row_half_mirror
+            WN_MERGE_DPP(0x140, 0xF);   // row_mirror
+            WN_MERGE_DPP(0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+            WN_MERGE_DPP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
 #undef WN_MERGE_DPP
-        {
-            // A largest |Z|^2 below 1e-30 or an energy above 1e30 (zero, or samples so small or
-            // so large that float32 squares lose their meaning, or not a number) is not decided
-            // here: the window goes to the float64 pass, which also recognises all-zero windows.
-            const float mxf = __uint_as_float(best.mx);
-            const bool odd = !(mxf >= 1e-30f && e_half <= 1e30f);
-            // Keys carry |Z|^2 truncated to 2^-11 relative.  The float32 value of every |Z|^2 is
-            // within err_lin*sqrt(|Z|^2 * E) + err_sq*E of the exact one (E = energy of the half
-            // spectrum; derivation at launch_detect), so a bin whose key value, rounded up, reaches
-            // `lim` may be the true maximum.  Outputs of column tiles that were left out are all
-            // below it.
-            const float f1 = __uint_as_float(best.k1 & ~KEY_BIN), f2 = __uint_as_float(best.k2 & ~KEY_BIN),
-                        f3 = __uint_as_float(best.k3 & ~KEY_BIN);
-            const float lim = (f1 - (err_lin * (sqrtf(mxf) * sqrtf(e_half)) + err_sq * e_half)) * keep;
-            // The magnitude that is reported must hold to 1e-4 relative as well.  Its float32 error
-            // is a few 1e-9 * sqrt(E) in practice (measured; the bound above is the worst case), so
-            // a searched maximum holding less than 1e-6 of the energy (nearly everything sits in the
-            // one bin that is not searched) is recomputed in float64 too.
-            const bool faint = e_half > 1e6f * mxf;
+            const float f2 = __uint_as_float(best.k2 & ~KEY_BIN), f3 = __uint_as_float(best.k3 & ~KEY_BIN);
             const bool full = odd | faint | (f3 >= lim), top2 = f2 >= lim;
             const int b = (int)(best.k1 & KEY_BIN);
             const unsigned cls = lut_s[odd ? 0 : b];
             pend_bin = full ? ((odd ? 0 : b) | FLAG_FULL) : (top2 ? (b | FLAG_TOP2) : b);
             pend_cls = full ? 0u : (top2 ? (best.k2 & KEY_BIN) : cls);
-            pend_mag = odd ? 0.f : sqrtf(mxf);
-            pend_w = w;
-            pend = true;
         }
         lap(ic<4>{});
         w = wn;
@@ -682,9 +698,9 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     flush();
     if (lane == 0 && cols_done) atomicAdd(&stats[3], cols_done);
     if constexpr (PROF) {
-        // out_bin[0..4]: clocks/256 per phase (DMA wait, stage 1, stores + next DMA issue,
-        // stage 2 with its arg-max work, merge + decision); [7]: total clocks/256;
-        // [8]: 100 MHz ticks/256
+        // out_bin[0..5]: clocks/256 per phase (DMA wait, stage 1, stores + next DMA issue,
+        // stage 2 with its arg-max work and checks, merge + decision, energies + tile order
+        // between the stages); [7]: total clocks/256; [8]: 100 MHz ticks/256
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             for (int i = 0; i < 7; ++i) out_bin[i] = (int)(prof[i] >> 8);
             out_bin[7] = (int)((__builtin_amdgcn_s_memtime() - prof_c0) >> 8);
