@@ -118,9 +118,11 @@ int wn_ctx_destroy(wn_ctx *ctx);
 int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
 /* Counters since the last call (synchronises `stream`): out[0] windows detected,
  * out[1] windows whose top two bins were re-evaluated in float64, out[2] windows whose
- * whole spectrum was.  One set of counters per context, summed over every thread and stream
- * that detects with it. */
-int wn_detect_stats(wn_ctx *ctx, int64_t out[3], void *stream);
+ * whole spectrum was, out[3] spectrum columns (k mod n2, folded: (n2+1)/2 per window at most)
+ * whose second DFT stage was computed; the rest were left out because the energy outside the
+ * outputs already seen could not reach the decision threshold.  One set of counters per
+ * context, summed over every thread and stream that detects with it. */
+int wn_detect_stats(wn_ctx *ctx, int64_t out[4], void *stream);
 
 /* ---- K4: checksum and frames ------------------------------------------------------- */
 /* calcular_checksum (B:178-187; A:89) over n messages: d_out[i] = zlib CRC-32 of

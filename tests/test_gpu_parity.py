@@ -435,6 +435,39 @@ def test_detect_float32_error_stays_inside_the_bound(mb):
     assert np.all(err <= bound / 8), (err / bound).max()
 
 
+def test_detect_leaves_out_only_columns_that_cannot_matter(mb, golden):
+    """The second DFT stage runs on 16 spectrum columns at a time and stops once the energy outside
+    the outputs seen cannot reach the decision threshold.  Clean tones need few columns, noise needs
+    all 43, a tone on the bin that is not searched needs all of them too; bins, classes and
+    magnitudes equal the oracle's whole-spectrum argmax in every case, and so do near-ties whose two
+    peaks sit in different column tiles."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    t = np.arange(7055)
+    rng = np.random.default_rng(31)
+    tones = np.concatenate([0.45 * np.sin(2 * np.pi * (350 + 70 * b) * t / 44100) for b in range(0, 256, 5)])
+    mb.detect_stats()
+    check_detect(mb, tones.astype(np.float32), 7055, lut)
+    w, _, _, cols = mb.detect_stats(columns=True)
+    assert w == 52 and cols < 30 * w                         # mostly one tile of 16 (or 11) columns
+    noise = 0.2 * rng.standard_normal(7055 * 8)
+    check_detect(mb, noise.astype(np.float32), 7055, lut)
+    w, _, _, cols = mb.detect_stats(columns=True)
+    assert (w, cols) == (8, 8 * 43)
+    # two tones of nearly equal strength whose bins fall into different column tiles (k mod 85,
+    # folded, in [0,16), [16,32), [32,43)), in both orders of strength, with and without a third
+    wins = []
+    for ka, kb in ((5, 20), (90, 2000), (40, 1300), (700, 37), (3000, 25)):
+        for eps in (1e-7, -1e-7, 1e-3, -1e-3, 0.2, -0.2):
+            x = np.cos(2 * np.pi * ka * t / 7055 + 0.3) + (1 + eps) * np.cos(2 * np.pi * kb * t / 7055 + 1.0)
+            wins.append(0.3 * x)
+            wins.append(0.3 * x + 0.29 * np.cos(2 * np.pi * 1717 * t / 7055))
+    check_detect(mb, np.concatenate(wins).astype(np.float32), 7055, lut)
+    # DC offset (bin 0 carries most of the energy) and a weak tone on top of it
+    dc = np.concatenate([0.5 + 0.01 * np.cos(2 * np.pi * 500 * t / 7055), 0.5 + 1e-4 * rng.standard_normal(7055),
+                         -0.7 + 0.3 * np.cos(2 * np.pi * 2222 * t / 7055)])
+    check_detect(mb, dc.astype(np.float32), 7055, lut)
+
+
 def test_detect_refinement_paths_forced(golden):
     """Raise the tie band so that the float64 re-evaluation runs on ordinary windows: both
     the two-bin and the whole-spectrum path must reproduce the oracle."""

@@ -211,10 +211,12 @@ class Modem:
     def set_tie_band(self, rel: float):
         L.check(L.lib.wn_detect_set_tie_band(self._ctx, float(rel)), "wn_detect_set_tie_band")
 
-    def detect_stats(self):
-        out = (C.c_int64 * 3)()
+    def detect_stats(self, columns: bool = False):
+        """[windows, two-bin float64 re-evaluations, whole-spectrum ones] since the last call; with
+        `columns` also the number of spectrum columns whose second stage was computed."""
+        out = (C.c_int64 * 4)()
         L.check(L.lib.wn_detect_stats(self._ctx, out, _stream()), "wn_detect_stats")
-        return list(out)
+        return list(out) if columns else list(out)[:3]
 
     def sync_scan(self, audio: torch.Tensor, n_streams: int, stream_stride: int, n_windows: int, first_sample: int = 0):
         """Ping correlator (the test of escuchar_ping, c1_shared.py:380-382) per window:
