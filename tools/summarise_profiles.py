@@ -9,7 +9,11 @@ committed summaries under profiles/:
   <tag>_kernelbench_kernel_stats.csv  rocprofv3 --kernel-trace --stats of tools/kernel_bench.py --reps 1
   <tag>_kernelbench_pmc.json          FETCH_SIZE / WRITE_SIZE passes of the same, per launch, largest launch per kernel
 
-    python tools/summarise_profiles.py <tag>
+    python tools/summarise_profiles.py <tag> [output directory [commit]]
+
+The rocprofv3 databases are too large to bring back from the GPU box, so the script is run there
+with gpurun_out/<tag>_profiles as output directory and the commit given on the command line; the
+files are then copied into profiles/ here.
 
 HBM bytes per kernel follow the rocprofv3 recipe for this chip: FETCH_SIZE and WRITE_SIZE are
 KiB; FETCH_SIZE counts 16-byte-per-lane streaming reads at half their size on gfx950, so
@@ -25,7 +29,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STREAMING_X4 = ("detect_kernel", "sync_kernel")
+STREAMING_X4 = ("detect_kernel", "sync_kernel", "crc_rows_kernel")
 
 
 def db(path):
@@ -80,16 +84,23 @@ def counters(src, subdirs, per="mean"):
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", tag)
-    dst = os.path.join(ROOT, "profiles", tag)
-    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+    os.makedirs(outdir, exist_ok=True)
+    dst = os.path.join(outdir, tag)
+    if len(sys.argv) > 3:
+        commit = sys.argv[3]
+    else:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     shutil.copy(os.path.join(src, "bench.json"), dst + "_bench.json")
     shutil.copy(os.path.join(src, "kernel_bench.jsonl"), dst + "_kernel_bench.jsonl")
     stats_csv(os.path.join(src, "stats"), dst + "_bench_kernel_stats.csv")
     with open(os.path.join(src, "bench.json")) as f:
         bench = json.loads(f.read().strip().splitlines()[-1])
-    notes = ("values are per launch; FETCH_SIZE and WRITE_SIZE are KiB; fetch_bytes_corrected doubles FETCH_SIZE "
-             "for the kernels that stream 16 bytes per lane (gfx950 counts those reads at half size)")
-    kernels = counters(src, ("pmc_fetch", "pmc_write", "pmc_sq"))
+    notes = ("values are per launch, of the largest launch of each kernel (the full-size one); FETCH_SIZE and WRITE_SIZE "
+             "are KiB; fetch_bytes_corrected doubles FETCH_SIZE for the kernels that stream 16 bytes per lane (gfx950 "
+             "counts those reads at half size)")
+    # the one-step run launches every kernel twice: a two-stream set-up pass, then the full-size step
+    kernels = counters(src, ("pmc_fetch", "pmc_write", "pmc_sq"), per="max")
     out = {
         "command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --cpu-streams 0 "
                    "--no-extras (one run per counter group: FETCH_SIZE; WRITE_SIZE; seven SQ counters)",
