@@ -51,18 +51,21 @@ WIN = 7055
 
 def detect_flop(n1: int, n2: int):
     """Algorithmic flop of the folded prime-factor DFT (multiply-adds of the matrix products
-    only, without tile padding) as (stage 1 per window, stage 2 per spectrum column).  Stage 1:
-    for each of n1 rows, real and imaginary part of h2 columns from h2 folded samples.  Stage 2:
-    four real sums over h1 folded rows for each of h1 output pairs of a column; a window has h2
-    columns, of which the kernel computes only those that can still change the decision."""
+    only, without tile padding) as (stage 1 per (row tile, column) product, stage 2 per spectrum
+    column).  Stage 1: for each of n1 rows, real and imaginary part of h2 columns from h2 folded
+    samples; its rows come in 2*ceil(h1/16) tiles (sums and differences of mirrored rows), and the
+    kernel counts the (row tile, column) products it computes.  Stage 2: four real sums over h1
+    folded rows for each of h1 output pairs of a column.  A window has h2 columns; the kernel
+    computes only what can still change the decision."""
     h1, h2 = n1 // 2 + 1, n2 // 2 + 1
-    return 2.0 * n1 * h2 * h2 * 2, 2.0 * h1 * h1 * 4
+    tiles = 2 * ((h1 + 15) // 16)
+    return 2.0 * n1 * h2 * h2 * 2 / (tiles * h2), 2.0 * h1 * h1 * 4, tiles
 
 
 def detect_flop_per_window(n1: int, n2: int) -> float:
     """The same with every column computed (the whole spectrum)."""
-    s1, s2 = detect_flop(n1, n2)
-    return s1 + s2 * (n2 // 2 + 1)
+    s1, s2, tiles = detect_flop(n1, n2)
+    return (s1 * tiles + s2) * (n2 // 2 + 1)
 
 
 def make_inputs(n, first_index, device):
@@ -383,10 +386,11 @@ def main():
         win_per_launch = sub * nwin
         # flop of what the launches computed: stage 1 of every window, stage 2 of the spectrum
         # columns the kernel did not leave out (counted by the kernel itself over the timed steps)
-        st_windows, _, _, st_columns = counters
-        s1_flop, s2_flop_per_col = detect_flop(n1, n2)
+        st_windows, _, _, st_columns, st_units = counters
+        s1_flop_per_unit, s2_flop_per_col, s1_tiles = detect_flop(n1, n2)
         cols_per_window = st_columns / max(st_windows, 1)
-        flop = (s1_flop + s2_flop_per_col * cols_per_window) * win_per_launch
+        units_per_window = st_units / max(st_windows, 1)
+        flop = (s1_flop_per_unit * units_per_window + s2_flop_per_col * cols_per_window) * win_per_launch
         achieved = flop / (det_ms * 1e-3) / 1e12
         # HBM traffic of a detection launch: not measurable from inside this process; taken from the
         # newest committed counter passes of this same command, only if they are of this kernel and
@@ -419,9 +423,11 @@ def main():
                          "ms_per_launch": det_ms,
                          "spectrum_columns_computed_per_window": cols_per_window,
                          "spectrum_columns_per_window": n2 // 2 + 1,
+                         "stage1_tile_columns_computed_per_window": units_per_window,
+                         "stage1_tile_columns_per_window": s1_tiles * (n2 // 2 + 1),
                          "flop_per_window_whole_spectrum": detect_flop_per_window(n1, n2),
-                         "note": "achieved counts the flop of the stages the kernel ran: stage 1 of every window and "
-                                 "stage 2 of the spectrum columns it could not rule out by the energy bound; with "
+                         "note": "achieved counts the flop of what the kernel ran: the parts of both DFT stages it could "
+                                 "not rule out by the energy bound (counted by the kernel); with "
                                  "the whole-spectrum figure per window the same time would read %.1f TFLOP/s"
                                  % (detect_flop_per_window(n1, n2) * win_per_launch / (det_ms * 1e-3) / 1e12)},
             "synth": {"bound": "hbm", "kernel": "synth_kernel<float>", "ms_per_launch": syn_ms,

@@ -447,12 +447,13 @@ def test_detect_leaves_out_only_columns_that_cannot_matter(mb, golden):
     tones = np.concatenate([0.45 * np.sin(2 * np.pi * (350 + 70 * b) * t / 44100) for b in range(0, 256, 5)])
     mb.detect_stats()
     check_detect(mb, tones.astype(np.float32), 7055, lut)
-    w, _, _, cols = mb.detect_stats(columns=True)
+    w, _, _, cols, s1 = mb.detect_stats(columns=True)
     assert w == 52 and cols < 30 * w                         # mostly one tile of 16 (or 11) columns
+    assert s1 < 0.7 * w * 6 * 43                             # and most of stage 1 was left out with them
     noise = 0.2 * rng.standard_normal(7055 * 8)
     check_detect(mb, noise.astype(np.float32), 7055, lut)
-    w, _, _, cols = mb.detect_stats(columns=True)
-    assert (w, cols) == (8, 8 * 43)
+    w, _, _, cols, s1 = mb.detect_stats(columns=True)
+    assert (w, cols, s1) == (8, 8 * 43, 8 * 6 * 43)
     # two tones of nearly equal strength whose bins fall into different column tiles (k mod 85,
     # folded, in [0,16), [16,32), [32,43)), in both orders of strength, with and without a third
     wins = []

@@ -20,7 +20,7 @@ struct wn_ctx {
     float2 *d_tw1;        // n1 entries (cos, sin)(2*pi*m/n1)
     float2 *d_tw2;        // n2 entries (cos, -sin)(2*pi*m/n2)
     double tie_band;
-    unsigned long long *d_stats;  // 4 counters
+    unsigned long long *d_stats;  // 8 counters (5 used)
     // sync: ping bins [lo, hi]
     int32_t ping_lo, ping_hi;
     // checksum: slicing-by-4 tables [4][256]

@@ -302,8 +302,8 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
         wn_host_crc_tables(tab);
         INIT_TRY(upload(&ctx->d_crc_tab, &tab[0][0], (size_t)4 * 256));
     }
-    INIT_HIP(hipMalloc((void **)&ctx->d_stats, 4 * sizeof(unsigned long long)));
-    INIT_HIP(hipMemset(ctx->d_stats, 0, 4 * sizeof(unsigned long long)));
+    INIT_HIP(hipMalloc((void **)&ctx->d_stats, 8 * sizeof(unsigned long long)));
+    INIT_HIP(hipMemset(ctx->d_stats, 0, 8 * sizeof(unsigned long long)));
     if ((size_t)ctx->n * sizeof(double2) > 150 * 1024) {
         wn_set_error("window length %d too large for the float64 phase table", ctx->n);
         wn_ctx_destroy(ctx);
@@ -336,13 +336,13 @@ extern "C" int wn_detect_set_tie_band(wn_ctx *ctx, double rel) {
     return WN_OK;
 }
 
-extern "C" int wn_detect_stats(wn_ctx *ctx, int64_t out[4], void *stream) {
+extern "C" int wn_detect_stats(wn_ctx *ctx, int64_t out[5], void *stream) {
     WN_REQUIRE(ctx && out, "ctx/out");
-    unsigned long long h[4];
+    unsigned long long h[8];
     hipStream_t st = (hipStream_t)stream;
     WN_HIP_TRY(hipMemcpyAsync(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost, st));
     WN_HIP_TRY(hipMemsetAsync(ctx->d_stats, 0, sizeof(h), st));
     WN_HIP_TRY(hipStreamSynchronize(st));
-    for (int i = 0; i < 4; ++i) out[i] = (int64_t)h[i];
+    for (int i = 0; i < 5; ++i) out[i] = (int64_t)h[i];
     return WN_OK;
 }

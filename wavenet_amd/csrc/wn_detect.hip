@@ -166,6 +166,7 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7"
 __device__ __forceinline__ void acc_const(float &dst, float v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); }
 // ties a register's later readers to this point of the (ordered) asm sequence
 __device__ __forceinline__ void after_drain(floatx4 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void after_drain_a(floatx4 &v) { asm volatile("" : "+a"(v)); }
 
 // (v.x + v.y, v.x - v.y) in one packed instruction
 __device__ __forceinline__ floatx2 pk_butterfly(floatx2 v) {
@@ -359,18 +360,19 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         });
         return off;
     };
-    // (stream, window) of the window to fetch next, advanced without divisions
+    // (stream, window) of the window in work and of the one after it, advanced without divisions
     const long long adv_s = wstep / n_windows, adv_w = wstep - adv_s * n_windows;
-    long long f_s = w / n_windows, f_w = w - f_s * n_windows;
-    auto fetch_next = [&]() {
-        const int off = fetch(f_s, f_w);
+    long long cur_s = w / n_windows, cur_w = w - cur_s * n_windows;
+    long long f_s = cur_s, f_w = cur_w;
+    auto advance = [&]() {   // the window after this wave's next one
+        cur_s = f_s;
+        cur_w = f_w;
         f_s += adv_s;
         f_w += adv_w;
         if (f_w >= n_windows) {
             f_w -= n_windows;
             f_s += 1;
         }
-        return off;
     };
 
     // Results of a window are stored one window later, just ahead of the next DMA issue, so
@@ -402,8 +404,12 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         }
     };
 
+    unsigned long long s1_units = 0;    // (row tile, column) pairs of stage 1 this wave computed (statistics)
     int next_off = 0;
-    if (w < total) next_off = fetch_next();
+    if (w < total) {
+        next_off = fetch(f_s, f_w);
+        advance();
+    }
     while (w < total) {
         if constexpr (PROF) prof_t = __builtin_amdgcn_s_memtime();
         const int xb = 4 * (xw_f + next_off);   // byte address of sample 0 of this window
@@ -417,120 +423,153 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         lap(ic<0>{});
 
         // ------------------------------------------------------------------ stage 1
-        floatx4 Yr[C2T][T1], Yi[C2T][T1];   // S (row tiles < TA) and D (row tiles >= TA), real and imaginary
+        // results: S (row tiles < TA) and D (row tiles >= TA), real and imaginary.  Whatever part of
+        // stage 1 writes them, the part of stage 2 that reads them follows on the same path through
+        // the code below, so that no two ways of producing them ever meet (where they would, the
+        // compiler copies whole sets of accumulation registers around).
+        floatx4 Yr[C2T][T1], Yi[C2T][T1];
         // samples and A operands as register pairs (row tile t, row tile t + TA), so that the
         // folds are packed f32 instructions: 4 per pair of row tiles instead of 8
         floatx2 raw_p[TA], raw_m[TA], xs[TA], xd[TA];
-        auto rd = [&](auto KS) {   // issue the sample reads of k-step KS
-            constexpr int ks = decltype(KS)::value;
-            static_for<T1>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                raw_p[t % TA][t / TA] = *(const float *)(smem + ad_p[t] + 4 * N1 * ks);
-                raw_m[t % TA][t / TA] = *(const float *)(smem + ad_m[t] + 4 * N1 * (KS1 - 1 - ks));
-            });
-        };
         floatx2 e4[TA];            // running sums of the squared A operands, per row-tile pair
-        auto fold = [&](auto KS) {   // samples read last -> A operands of k-step KS: fold columns, then rows
-            constexpr int ks = decltype(KS)::value;
-            static_for<TA>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                const floatx2 sab = raw_p[t] + raw_m[t], dab = raw_p[t] - raw_m[t];   // (sa, sb), (da, db)
-                xs[t] = pk_butterfly(sab);                                            // (sa + sb, sa - sb)
-                xd[t] = pk_butterfly(dab);
-                if constexpr (ks == 0) {
-                    e4[t] = (xs[t] * xs[t] + xd[t] * xd[t]) * w_first;
-                } else if constexpr (ks == KS1 - 1) {
-                    e4[t] += (xs[t] * xs[t] + xd[t] * xd[t]) * w_last;
-                } else {
-                    e4[t] += xs[t] * xs[t];
-                    e4[t] += xd[t] * xd[t];
-                }
-                // keeps the sums here, between the matrix instructions of two k-steps (left to
-                // itself the compiler holds every k-step's operands and squares them after stage 1)
-                asm volatile("" : "+v"(e4[t]));
-            });
-        };
-        rd(ic<0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        fold(ic<0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (KS1 > 1) rd(ic<1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<KS1>([&](auto KS) {
-            constexpr int ks = decltype(KS)::value;
-            static_for<C2T>([&](auto C) {
-                static_for<T1>([&](auto T) {
-                    constexpr int c = decltype(C)::value, t = decltype(T)::value;
-                    if constexpr (ks == 0) {
-                        mfma1_new(Yr[c][t], xs[t % TA][t / TA], t2c[ks][c]);
-                        mfma1_new(Yi[c][t], xd[t % TA][t / TA], t2s[ks][c]);
-                    } else {
-                        mfma1_acc(Yr[c][t], xs[t % TA][t / TA], t2c[ks][c]);
-                        mfma1_acc(Yi[c][t], xd[t % TA][t / TA], t2s[ks][c]);
+        floatx2 sx[TA];            // running sums of the A operands (.x: the sum of the four samples)
+        // Stage 1 comes in three cuts.  PILOT: the sum row tile 0 (rows a' < 16) of every column
+        // tile, from which the energy of each column tile is estimated.  WHOLE: every other row
+        // tile of every column tile.  ONE<c>: every other row tile of column tile c only, for
+        // windows whose energy the pilot finds in one column tile.
+        constexpr int PILOT = 0, WHOLE = 1, ONE = 2;
+        auto stage1 = [&](auto CUT_, auto CSEL_) {
+            constexpr int CUT = decltype(CUT_)::value, CSEL = decltype(CSEL_)::value;
+            constexpr int NP = CUT == PILOT ? 1 : TA;   // row-tile pairs gathered
+            auto rd = [&](auto KS) {   // issue the sample reads of k-step KS
+                constexpr int ks = decltype(KS)::value;
+                static_for<NP>([&](auto PR) {
+                    constexpr int pr = decltype(PR)::value;
+                    raw_p[pr][0] = *(const float *)(smem + ad_p[pr] + 4 * N1 * ks);
+                    raw_m[pr][0] = *(const float *)(smem + ad_m[pr] + 4 * N1 * (KS1 - 1 - ks));
+                    raw_p[pr][1] = *(const float *)(smem + ad_p[pr + TA] + 4 * N1 * ks);
+                    raw_m[pr][1] = *(const float *)(smem + ad_m[pr + TA] + 4 * N1 * (KS1 - 1 - ks));
+                });
+            };
+            auto fold = [&](auto KS) {   // samples read last -> A operands of k-step KS: fold columns, then rows
+                constexpr int ks = decltype(KS)::value;
+                static_for<NP>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    const floatx2 sab = raw_p[t] + raw_m[t], dab = raw_p[t] - raw_m[t];   // (sa, sb), (da, db)
+                    xs[t] = pk_butterfly(sab);                                            // (sa + sb, sa - sb)
+                    xd[t] = pk_butterfly(dab);
+                    if constexpr (CUT != PILOT) {
+                        if constexpr (ks == 0) {
+                            e4[t] = (xs[t] * xs[t] + xd[t] * xd[t]) * w_first;
+                            sx[t] = xs[t] * w_first;
+                        } else if constexpr (ks == KS1 - 1) {
+                            e4[t] += (xs[t] * xs[t] + xd[t] * xd[t]) * w_last;
+                            sx[t] += xs[t] * w_last;
+                        } else {
+                            e4[t] += xs[t] * xs[t];
+                            e4[t] += xd[t] * xd[t];
+                            sx[t] += xs[t];
+                        }
+                        // keeps the sums here, between the matrix instructions of two k-steps (left to
+                        // itself the compiler holds every k-step's operands and squares them after stage 1)
+                        asm volatile("" : "+v"(e4[t]), "+v"(sx[t]));
                     }
                 });
-            });
+            };
+            rd(ic<0>{});
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ks + 1 < KS1) {
-                fold(ic<ks + 1>{});                        // operands of k-step ks+1 (read before this k-step's MFMAs)
+            fold(ic<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KS1 > 1) rd(ic<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<KS1>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value;
+                static_for<C2T>([&](auto C) {
+                    static_for<T1>([&](auto T) {
+                        constexpr int c = decltype(C)::value, t = decltype(T)::value;
+                        constexpr bool mine = CUT == PILOT ? t == 0 : (t != 0 && (CUT == WHOLE || c == CSEL));
+                        if constexpr (mine) {
+                            if constexpr (ks == 0) {
+                                mfma1_new(Yr[c][t], xs[t % TA][t / TA], t2c[ks][c]);
+                                mfma1_new(Yi[c][t], xd[t % TA][t / TA], t2s[ks][c]);
+                            } else {
+                                mfma1_acc(Yr[c][t], xs[t % TA][t / TA], t2c[ks][c]);
+                                mfma1_acc(Yi[c][t], xd[t % TA][t / TA], t2s[ks][c]);
+                            }
+                        }
+                    });
+                });
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ks + 2 < KS1)
-                    rd(ic<ks + 2>{});
-                else
-                    asm volatile("s_nop 1" ::: "memory");   // operands just written, read by the next MFMA
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-        lap(ic<1>{});
-
-        // every LDS read of this window has returned (its values fed the MFMAs above):
-        // store the previous window's results, then start the next window's DMA so that it
-        // lands while stage 2 runs
-        const long long wn = w + wstep;
-        flush();
-        if (wn < total) next_off = fetch_next();
-        lap(ic<2>{});
-        mfma_drain();
-
-        // ------------------------------------------------------------------ between the stages
-        // Energy of the half spectrum the reference searches, E = sum_{k <= N/2} |X_k|^2
-        // = (N * sum x^2 + X_0^2) / 2 (N odd), from the samples: an upper bound for every bin and
-        // the scale of the float32 error.  X_0 = sum x is the sum of column k2 = 0 of the stage-1
-        // results (lanes with li = 0, sum tiles, rows a' <= h1, the self-mirrored row halved).
-        // Rough energy of each column tile of stage 1 (four rows of it): the order in which
-        // stage 2 takes the column tiles.
-        float e4l = 0.f;
-#pragma unroll
-        for (int t = 0; t < TA; ++t) e4l = fmaf(e4[t].x + e4[t].y, w_row[t], e4l);
-        float x0l = 0.f;
-        static_for<TA>([&](auto T) {
-            static_for<4>([&](auto R) {
-                constexpr int t = decltype(T)::value, r = decltype(R)::value, a0 = 16 * t + 4 * r;
-                if constexpr (a0 <= H1) {
-                    float v = Yr[0][t][r];
-                    if constexpr (a0 + 3 > H1) v = (a0 + lg <= H1) ? v : 0.f;
-                    if constexpr (a0 == 0) v = lg == 0 ? 0.5f * v : v;
-                    x0l += v;
+                if constexpr (ks + 1 < KS1) {
+                    fold(ic<ks + 1>{});                        // operands of k-step ks+1 (read before this k-step's MFMAs)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (ks + 2 < KS1)
+                        rd(ic<ks + 2>{});
+                    else
+                        asm volatile("s_nop 1" ::: "memory");   // operands just written, read by the next MFMA
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             });
-        });
-        float ec[C2T];
+        };
+        // every LDS read of this window has returned (its values fed the MFMAs of stage 1): store
+        // the previous window's results, then start the next window's DMA so that it lands
+        // while stage 2 runs
+        const long long wn = w + wstep;
+        auto next_window_dma = [&]() {
+            flush();
+            if (wn < total) next_off = fetch(f_s, f_w);
+        };
+        // Energy of the half spectrum the reference searches, E = sum_{k <= N/2} |X_k|^2
+        // = (N * sum x^2 + X_0^2) / 2 (N odd), from the samples gathered by stage 1: an upper
+        // bound for every bin and the scale of the float32 error.  Wave-uniform.
+        float e_half = 0.f, sqrt_e = 0.f;
+        auto energies = [&]() {
+            float e4l = 0.f, sxl = 0.f;
 #pragma unroll
-        for (int c = 0; c < C2T; ++c)
-            ec[c] = Yr[c][0][0] * Yr[c][0][0] + Yi[c][0][0] * Yi[c][0][0] + Yr[c][TA][0] * Yr[c][TA][0] +
-                    Yi[c][TA][0] * Yi[c][TA][0];
-        const float sx2 = 0.25f * lane63(wave_sum63(e4l));
-        // column k2 = 0 lives in the lanes with li = 0: lanes 0, 16, 32, 48
-        const float x0 = (lane_f(x0l, 0) + lane_f(x0l, 16)) + (lane_f(x0l, 32) + lane_f(x0l, 48));
-        const float e_half = 0.5f * fmaf((float)N, sx2, x0 * x0) * (1.f + 1e-5f);   // wave-uniform from here on
-        const float sqrt_e = __builtin_amdgcn_sqrtf(e_half);
-        lap(ic<5>{});
+            for (int t = 0; t < TA; ++t) {
+                e4l = fmaf(e4[t].x + e4[t].y, w_row[t], e4l);
+                sxl = fmaf(sx[t].x, w_row[t], sxl);
+            }
+            const float sx2 = 0.25f * lane63(wave_sum63(e4l)), x0 = lane63(wave_sum63(sxl));
+            e_half = 0.5f * fmaf((float)N, sx2, x0 * x0) * (1.f + 1e-5f);
+            sqrt_e = __builtin_amdgcn_sqrtf(e_half);
+        };
 
-        // ------------------------------------------------------------------ stage 2
+        stage1(ic<PILOT>{}, ic<0>{});
+        s1_units += P::K2;
+        mfma_drain();
+        // rough energy of each column tile (rows a' < 16 of it, mirrored pairs summed): where the
+        // second stage starts, and whether one column tile holds nearly everything
+        float ec[C2T];
+        unsigned eo[C2T];
+#pragma unroll
+        for (int c = 0; c < C2T; ++c) {
+            after_drain_a(Yr[c][0]);
+            after_drain_a(Yi[c][0]);
+            const floatx4 yr = Yr[c][0], yi = Yi[c][0];
+            ec[c] = (yr.x * yr.x + yi.x * yi.x) + (yr.y * yr.y + yi.y * yi.y) + (yr.z * yr.z + yi.z * yi.z) +
+                    (yr.w * yr.w + yi.w * yi.w);
+            eo[c] = lane63(__float_as_uint(wave_sum63(ec[c])));   // non-negative floats order like their bits
+        }
+        int c_first = 0;
+        bool one_tile;
+        {
+            unsigned top = eo[0];
+            float tot = __uint_as_float(eo[0]);
+#pragma unroll
+            for (int c = 1; c < C2T; ++c) {
+                tot += __uint_as_float(eo[c]);
+                if (eo[c] > top) {
+                    top = eo[c];
+                    c_first = c;
+                }
+            }
+            one_tile = __uint_as_float(top) >= 0.7f * tot && tot <= 1e30f;   // false for anything that is not a number
+        }
+        lap(ic<1>{});
+
         Top3 best;
-        best.k1 = best.k2 = best.k3 = 0u;
-        best.mx = 0u;
-        float eproc = 0.f;   // energy of the outputs this lane has looked at (each bin once)
+        float eproc;   // energy of the outputs this lane has looked at (each bin once)
         auto col_tile = [&](auto C) {   // every output with k2 in column tile C
             constexpr int c = decltype(C)::value;
             floatx4 acc[TA][4];   // the sums A, B, C, E of each row tile
@@ -605,40 +644,94 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             return e_half * 1.005f - seen * (1.f - 1e-5f) < lim_now;
         };
         constexpr int NCOL[3] = {16, C2T > 2 ? 16 : P::K2 - 16, P::K2 - 16 * (C2T - 1)};
-        // The column tile with the largest rough energy first (any order is valid; this one ends
-        // the loop soonest), chosen again among the rest each time the loop has to go on.
-        unsigned todo = (1u << C2T) - 1u;
+        constexpr int OTHER_TILES = T1 - 1;   // row tiles of stage 1 beside the pilot's
+
+        // ------------------------------------------------------------------ the rest of stage 1, stage 2
+        auto after_stage1 = [&]() {
+            next_window_dma();
+            lap(ic<2>{});
+            mfma_drain();
+            energies();
+            lap(ic<5>{});
+            best.k1 = best.k2 = best.k3 = 0u;
+            best.mx = 0u;
+            eproc = 0.f;
+        };
         unsigned mxu = 0u;
         bool have_max = false;
-#pragma nounroll
-        for (int i = 0; i < C2T; ++i) {
-            int c;
-            if (i == C2T - 1) {
-                c = __ffs((int)todo) - 1;
-            } else {
-                unsigned key = 0u;   // energy bits (non-negative floats order like their bits), tile number in the low bits
-#pragma unroll
-                for (int q = 0; q < C2T; ++q)
-                    key = max(key, ((todo >> q) & 1u) ? ((__float_as_uint(ec[q]) & ~7u) | 4u | (unsigned)q) : 0u);
-                c = (int)(lane63(wave_max63(key)) & 3u);
-            }
-            todo &= ~(1u << c);
-            if (c == 0) {
+        bool whole = !one_tile;
+        if (one_tile) {
+            // the pilot found the energy in one column tile: stage 1 and stage 2 of that tile only
+            if (c_first == 0) {
+                stage1(ic<ONE>{}, ic<0>{});
+                after_stage1();
                 col_tile(ic<0>{});
-                cols_done += 16;
-            } else if (c == 1) {
+            } else if (c_first == 1) {
+                stage1(ic<ONE>{}, ic<1>{});
+                after_stage1();
                 col_tile(ic<1>{});
-                cols_done += NCOL[1];
-            } else {
-                if constexpr (C2T > 2) col_tile(ic<2>{});
-                cols_done += NCOL[2];
+            } else if constexpr (C2T > 2) {
+                stage1(ic<ONE>{}, ic<2>{});
+                after_stage1();
+                col_tile(ic<2>{});
             }
-            if (i + 1 < C2T && rest_cannot_matter(mxu)) {
+            const int ncol = c_first == 0 ? NCOL[0] : (c_first == 1 ? NCOL[1] : NCOL[2]);
+            s1_units += (unsigned)(OTHER_TILES * ncol);
+            cols_done += (unsigned)ncol;
+            if (rest_cannot_matter(mxu)) {
                 have_max = true;
-                break;
+            } else {
+                // Other column tiles are needed after all (energy in one column tile, but spread
+                // over many bins: rare).  The window's buffer is by now being overwritten by the
+                // next window: wait for that DMA, fetch this window again and do it the whole way
+                // (which fetches the next window again).
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                (void)fetch(cur_s, cur_w);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                whole = true;
+            }
+        }
+        if (whole) {
+            // every column tile gets its stage 1; stage 2 takes the one with the largest rough
+            // energy first (any order is valid; this one ends the loop soonest) and chooses again
+            // among the rest each time it has to go on
+            stage1(ic<WHOLE>{}, ic<0>{});
+            s1_units += OTHER_TILES * P::K2;
+            after_stage1();
+            unsigned todo = (1u << C2T) - 1u;
+#pragma nounroll
+            for (int i = 0; i < C2T; ++i) {
+                int c;
+                if (i == 0) {
+                    c = c_first;
+                } else if (i == C2T - 1) {
+                    c = __ffs((int)todo) - 1;
+                } else {
+                    unsigned key = 0u;   // energy bits, tile number in the low bits
+#pragma unroll
+                    for (int q = 0; q < C2T; ++q)
+                        key = max(key, ((todo >> q) & 1u) ? ((eo[q] & ~7u) | 4u | (unsigned)q) : 0u);
+                    c = (int)(key & 3u);
+                }
+                todo &= ~(1u << c);
+                if (c == 0) {
+                    col_tile(ic<0>{});
+                    cols_done += 16;
+                } else if (c == 1) {
+                    col_tile(ic<1>{});
+                    cols_done += NCOL[1];
+                } else {
+                    if constexpr (C2T > 2) col_tile(ic<2>{});
+                    cols_done += NCOL[2];
+                }
+                if (i + 1 < C2T && rest_cannot_matter(mxu)) {
+                    have_max = true;
+                    break;
+                }
             }
         }
         lap(ic<3>{});
+        if (wn < total) advance();
         if (!have_max) mxu = lane63(wave_max63(best.mx));
         // From here on `mxu`, and everything computed from it, is the same in every lane.
         // A largest |Z|^2 below 1e-30 or an energy above 1e30 (zero, or samples so small or so
@@ -696,7 +789,10 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         w = wn;
     }
     flush();
-    if (lane == 0 && cols_done) atomicAdd(&stats[3], cols_done);
+    if (lane == 0 && cols_done) {
+        atomicAdd(&stats[3], cols_done);
+        atomicAdd(&stats[4], s1_units);
+    }
     if constexpr (PROF) {
         // out_bin[0..5]: clocks/256 per phase (DMA wait, stage 1, stores + next DMA issue,
         // stage 2 with its arg-max work and checks, merge + decision, energies + tile order
