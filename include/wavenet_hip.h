@@ -117,14 +117,16 @@ int wn_ctx_destroy(wn_ctx *ctx);
  * context is shared, not concurrently with detection on it. */
 int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
 /* Counters since the last call (synchronises `stream`): out[0] windows detected,
- * out[1] windows whose top two bins were re-evaluated in float64, out[2] windows whose
- * whole spectrum was; and how much of the two DFT stages the kernel computed: out[3] spectrum
+ * out[1] windows whose two or three candidate bins were re-evaluated in float64, out[2] windows
+ * whose whole spectrum was; and how much of the two DFT stages the kernel computed: out[3] spectrum
  * columns (k mod n2, folded: (n2+1)/2 per window at most) whose second stage was computed,
  * out[4] (row tile of 16, column) products of the first stage (((n1+1)/2 + 15)/16*2 tiles times
- * (n2+1)/2 columns per window at most).  The rest was left out because the energy outside the
- * outputs already seen could not reach the decision threshold.  One set of counters per
- * context, summed over every thread and stream that detects with it. */
-int wn_detect_stats(wn_ctx *ctx, int64_t out[5], void *stream);
+ * (n2+1)/2 columns per window at most), out[5] windows that were started on one column tile and
+ * had to be done again on all of them (their work is counted twice in out[3], out[4]).  The rest
+ * was left out because the energy outside the outputs already seen could not reach the decision
+ * threshold.  One set of counters per context, summed over every thread and stream that detects
+ * with it. */
+int wn_detect_stats(wn_ctx *ctx, int64_t out[6], void *stream);
 
 /* ---- K4: checksum and frames ------------------------------------------------------- */
 /* calcular_checksum (B:178-187; A:89) over n messages: d_out[i] = zlib CRC-32 of

@@ -447,12 +447,12 @@ def test_detect_leaves_out_only_columns_that_cannot_matter(mb, golden):
     tones = np.concatenate([0.45 * np.sin(2 * np.pi * (350 + 70 * b) * t / 44100) for b in range(0, 256, 5)])
     mb.detect_stats()
     check_detect(mb, tones.astype(np.float32), 7055, lut)
-    w, _, _, cols, s1 = mb.detect_stats(columns=True)
+    w, _, _, cols, s1, _ = mb.detect_stats(columns=True)
     assert w == 52 and cols < 30 * w                         # mostly one tile of 16 (or 11) columns
     assert s1 < 0.7 * w * 6 * 43                             # and most of stage 1 was left out with them
     noise = 0.2 * rng.standard_normal(7055 * 8)
     check_detect(mb, noise.astype(np.float32), 7055, lut)
-    w, _, _, cols, s1 = mb.detect_stats(columns=True)
+    w, _, _, cols, s1, _ = mb.detect_stats(columns=True)
     assert (w, cols, s1) == (8, 8 * 43, 8 * 6 * 43)
     # two tones of nearly equal strength whose bins fall into different column tiles (k mod 85,
     # folded, in [0,16), [16,32), [32,43)), in both orders of strength, with and without a third
@@ -498,6 +498,24 @@ def test_detect_near_tie_decided_in_float64(mb, golden):
     mb.detect_stats()
     check_detect(mb, x32, 7055, lut)
     assert mb.detect_stats()[1] >= 3
+
+
+def test_detect_three_way_near_tie(mb, golden):
+    """Three tones whose peaks float32 cannot order: the three candidates are re-evaluated in
+    float64 (not the whole spectrum) and the oracle's bin wins; with four such tones the whole
+    spectrum is."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    n = np.arange(7055)
+    wins = []
+    for e2, e3 in ((1e-7, -1e-7), (-2e-7, 1e-7), (0.0, 0.0), (3e-7, 2e-7)):
+        wins.append(np.cos(2 * np.pi * 300 * n / 7055) + (1 + e2) * np.cos(2 * np.pi * 1500 * n / 7055 + 0.3)
+                    + (1 + e3) * np.cos(2 * np.pi * 2900 * n / 7055 + 1.3))
+    four = sum(np.cos(2 * np.pi * k * n / 7055 + 0.1 * k) for k in (300, 1100, 1900, 2700))
+    x32 = (0.3 * np.concatenate(wins + [four])).astype(np.float32)
+    mb.detect_stats()
+    check_detect(mb, x32, 7055, lut)
+    _, few, whole = mb.detect_stats()
+    assert few >= 3 and whole <= 2
 
 
 def test_detect_scheme_a(ma, golden):

@@ -64,9 +64,10 @@
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
-#define FLAG_TOP2 (1 << 30)
-#define FLAG_FULL (1 << 29)
-#define FLAG_MASK (FLAG_TOP2 | FLAG_FULL)
+#define FLAG_TOP2 (1 << 30)   // two candidate bins: this one and the one in the class word
+#define FLAG_FULL (1 << 29)   // the whole spectrum
+#define FLAG_TOP3 (1 << 28)   // three candidates: the third in the magnitude word (as an integer)
+#define FLAG_MASK (FLAG_TOP2 | FLAG_FULL | FLAG_TOP3)
 #define KEY_BIN 0xFFFu   // low bits of a key hold the bin
 #define EP_UNUSED 0x8000u
 
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     };
 
     unsigned long long s1_units = 0;    // (row tile, column) pairs of stage 1 this wave computed (statistics)
+    unsigned long long redone = 0;      // windows done a second time, the whole way
     int next_off = 0;
     if (w < total) {
         next_off = fetch(f_s, f_w);
@@ -689,6 +691,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 (void)fetch(cur_s, cur_w);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 whole = true;
+                ++redone;
             }
         }
         if (whole) {
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         const bool faint = e_half > 1e6f * mxf;
         const unsigned long long in1 = __ballot(__uint_as_float(best.k1 & ~KEY_BIN) >= lim);
         const unsigned long long in2 = __ballot(__uint_as_float(best.k2 & ~KEY_BIN) >= lim);
+        const unsigned long long in3 = __ballot(__uint_as_float(best.k3 & ~KEY_BIN) >= lim);
         pend_mag = odd ? 0.f : __builtin_amdgcn_sqrtf(mxf);
         pend_w = w;
         pend = true;
@@ -778,12 +782,17 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             WN_MERGE_DPP(0x142, 0xA);   // row_bcast:15 into rows 1 and 3
             WN_MERGE_DPP(0x143, 0xC);   // row_bcast:31 into rows 2 and 3
 #undef WN_MERGE_DPP
-            const float f2 = __uint_as_float(best.k2 & ~KEY_BIN), f3 = __uint_as_float(best.k3 & ~KEY_BIN);
-            const bool full = odd | faint | (f3 >= lim), top2 = f2 >= lim;
+            // Outputs that reach the limit, counted over the lanes before the merge: a lane's three
+            // slots are three different outputs.  Up to three, none of them a lane's third (a lane
+            // whose third reaches the limit may hold a fourth that does): exactly those are the
+            // candidates, and the merged top three name them.  More: the whole spectrum.
+            const int cand = __popcll(in1) + __popcll(in2) + __popcll(in3);
+            const bool full = odd | faint | (in3 != 0ull) | (cand > 3);
             const int b = (int)(best.k1 & KEY_BIN);
             const unsigned cls = lut_s[odd ? 0 : b];
-            pend_bin = full ? ((odd ? 0 : b) | FLAG_FULL) : (top2 ? (b | FLAG_TOP2) : b);
-            pend_cls = full ? 0u : (top2 ? (best.k2 & KEY_BIN) : cls);
+            pend_bin = full ? ((odd ? 0 : b) | FLAG_FULL) : (cand == 3 ? (b | FLAG_TOP3) : (cand == 2 ? (b | FLAG_TOP2) : b));
+            pend_cls = full ? 0u : (cand >= 2 ? (best.k2 & KEY_BIN) : cls);
+            if (!full && cand == 3) pend_mag = __int_as_float((int)(best.k3 & KEY_BIN));
         }
         lap(ic<4>{});
         w = wn;
@@ -792,6 +801,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     if (lane == 0 && cols_done) {
         atomicAdd(&stats[3], cols_done);
         atomicAdd(&stats[4], s1_units);
+        if (redone) atomicAdd(&stats[5], redone);
     }
     if constexpr (PROF) {
         // out_bin[0..5]: clocks/256 per phase (DMA wait, stage 1, stores + next DMA issue,
@@ -823,7 +833,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                                                      int32_t *__restrict__ bin, unsigned long long *stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     double2 *tw = (double2 *)smem;  // N entries
-    __shared__ double red[4][4];
+    __shared__ double red[4][6];
     __shared__ double best_m[4];
     __shared__ int best_b[4];
     __shared__ unsigned long long flagged[4];
@@ -858,26 +868,39 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
             const float *x = audio + s * stream_stride + first_sample + (wi - s * n_windows) * (long long)N;
             int rb;
             double rm;
-            if (f & FLAG_TOP2) {
-                const int b1 = f & 0xFFFF, b2 = cls[wi];
-                double r1 = 0, i1 = 0, r2 = 0, i2 = 0;
+            if (f & (FLAG_TOP2 | FLAG_TOP3)) {
+                const bool three = (f & FLAG_TOP3) != 0;
+                const int b1 = f & 0xFFFF, b2 = cls[wi], b3 = three ? __float_as_int(mag[wi]) : b1;
+                double r1 = 0, i1 = 0, r2 = 0, i2 = 0, r3 = 0, i3 = 0;
                 for (int n = tid; n < N; n += 256) {
                     const double xv = (double)x[n];
                     const double2 t1 = tw[(unsigned)(b1 * n) % (unsigned)N];
                     const double2 t2 = tw[(unsigned)(b2 * n) % (unsigned)N];
                     r1 += xv * t1.x; i1 += xv * t1.y;
                     r2 += xv * t2.x; i2 += xv * t2.y;
+                    if (three) {
+                        const double2 t3 = tw[(unsigned)(b3 * n) % (unsigned)N];
+                        r3 += xv * t3.x; i3 += xv * t3.y;
+                    }
                 }
                 r1 = wave_sum(r1); i1 = wave_sum(i1); r2 = wave_sum(r2); i2 = wave_sum(i2);
+                r3 = wave_sum(r3); i3 = wave_sum(i3);
                 __syncthreads();
-                if (lane == 0) { red[wave][0] = r1; red[wave][1] = i1; red[wave][2] = r2; red[wave][3] = i2; }
+                if (lane == 0) {
+                    red[wave][0] = r1; red[wave][1] = i1; red[wave][2] = r2; red[wave][3] = i2;
+                    red[wave][4] = r3; red[wave][5] = i3;
+                }
                 __syncthreads();
-                double v[4];
-                for (int q = 0; q < 4; ++q) v[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+                double v[6];
+                for (int q = 0; q < 6; ++q) v[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
                 const double ma = v[0] * v[0] + v[1] * v[1], mb = v[2] * v[2] + v[3] * v[3];
                 const bool first = (ma > mb) || (ma == mb && b1 < b2);
                 rb = first ? b1 : b2;
                 rm = first ? ma : mb;
+                if (three) {
+                    const double mc = v[4] * v[4] + v[5] * v[5];
+                    if (mc > rm || (mc == rm && b3 < rb)) { rb = b3; rm = mc; }
+                }
                 if (tid == 0) atomicAdd(&stats[1], 1ull);
             } else {
                 // all-zero windows (digital silence) need no spectrum: np.argmax of zeros is 0

@@ -213,9 +213,9 @@ class Modem:
 
     def detect_stats(self, columns: bool = False):
         """[windows, two-bin float64 re-evaluations, whole-spectrum ones] since the last call; with
-        `columns` also the spectrum columns whose second stage was computed and the (row tile,
-        column) products of the first stage that were."""
-        out = (C.c_int64 * 5)()
+        `columns` also the spectrum columns whose second stage was computed, the (row tile,
+        column) products of the first stage that were, and the windows that were done twice."""
+        out = (C.c_int64 * 6)()
         L.check(L.lib.wn_detect_stats(self._ctx, out, _stream()), "wn_detect_stats")
         return list(out) if columns else list(out)[:3]
 
