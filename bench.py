@@ -54,11 +54,11 @@ def detect_flop(n1: int, n2: int):
     only, without tile padding) as (stage 1 per (row tile, column) product, stage 2 per spectrum
     column).  Stage 1: for each of n1 rows, real and imaginary part of h2 columns from h2 folded
     samples; its rows come in 2*ceil(h1/16) tiles (sums and differences of mirrored rows), and the
-    kernel counts the (row tile, column) products it computes.  Stage 2: four real sums over h1
+    kernel counts the (row tile, real or imaginary part, column) products it computes.  Stage 2: four real sums over h1
     folded rows for each of h1 output pairs of a column.  A window has h2 columns; the kernel
     computes only what can still change the decision."""
     h1, h2 = n1 // 2 + 1, n2 // 2 + 1
-    tiles = 2 * ((h1 + 15) // 16)
+    tiles = 2 * 2 * ((h1 + 15) // 16)      # row tiles of sums and of differences, real and imaginary part each
     return 2.0 * n1 * h2 * h2 * 2 / (tiles * h2), 2.0 * h1 * h1 * 4, tiles
 
 

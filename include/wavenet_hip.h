@@ -120,8 +120,8 @@ int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
  * out[1] windows whose two or three candidate bins were re-evaluated in float64, out[2] windows
  * whose whole spectrum was; and how much of the two DFT stages the kernel computed: out[3] spectrum
  * columns (k mod n2, folded: (n2+1)/2 per window at most) whose second stage was computed,
- * out[4] (row tile of 16, column) products of the first stage (((n1+1)/2 + 15)/16*2 tiles times
- * (n2+1)/2 columns per window at most), out[5] windows that were started on one column tile and
+ * out[4] (row tile of 16, real or imaginary part, column) products of the first stage
+ * (((n1+1)/2 + 15)/16*2 tiles times 2 times (n2+1)/2 columns per window at most), out[5] windows that were started on one column tile and
  * had to be done again on all of them (their work is counted twice in out[3], out[4]).  The rest
  * was left out because the energy outside the outputs already seen could not reach the decision
  * threshold.  One set of counters per context, summed over every thread and stream that detects

@@ -25,7 +25,8 @@ fields[:, 13] = 3
 fields[:, 14] = 107
 frames, lens = m.build_frames(fields.cuda(), torch.randint(0, 256, (S, 112), dtype=torch.uint8, generator=g).cuda(), 128)
 clean, _ = m.encode_streams(frames, lens, stride)
-names = ["dma wait", "stage 1", "stores + next dma", "stage 2 + arg-max", "merge + decision", "energies + order"]
+names = ["dma wait", "pilot + tile energies", "stores + next dma", "stage 2 + arg-max", "decision", "window energy",
+         "rest of stage 1"]
 for what, audio in (("noise", 0.3 * torch.randn((S, stride), device="cuda")), ("clean frames", clean)):
     for i in range(3):
         m.detect_stats()
@@ -35,6 +36,6 @@ for what, audio in (("noise", 0.3 * torch.randn((S, stride), device="cuda")), ("
     nw = (S * nwin + 1023) // 1024
     print(what)
     for n, c in zip(names, v):
-        print("  %-20s %8.0f clocks/window" % (n, c * 256.0 / nw))
-    print("  %-20s %8.0f clocks/window" % ("total", v[7] * 256.0 / nw))
+        print("  %-22s %8.0f clocks/window" % (n, c * 256.0 / nw))
+    print("  %-22s %8.0f clocks/window" % ("total", v[7] * 256.0 / nw))
     print("  shader clock %.3f GHz" % (v[7] / v[8] * 0.1))

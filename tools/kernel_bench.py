@@ -94,7 +94,7 @@ def main():
             h1 = n1 // 2 + 1
             cols = st[3] / max(st[0], 1)            # spectrum columns whose second stage was computed, per window
             units = st[4] / max(st[0], 1)           # (row tile, column) products of the first stage, per window
-            tiles = 2 * ((h1 + 15) // 16)
+            tiles = 4 * ((h1 + 15) // 16)           # row tiles of sums / differences x real / imaginary part
             flop = (2.0 * n1 * k2 * k2 * 2 * units / (tiles * k2) + 2.0 * h1 * cols * h1 * 4) * S * nwin
             out.append({"kernel": "detect_kernel<83,85>+refine", "bound": "mfma", "ms": mean, "ms_min": best,
                         "algorithmic_flop": flop, "achieved_TFLOPs": flop / mean / 1e9, "peak_TFLOPs": 157.3,
@@ -180,7 +180,7 @@ def main():
         ok = bool(((cls[:, :msg] & 0x1FF).to(torch.uint8) == rows[:, :msg]).all())
         n1, n2 = M.host_dft_plan(ma.esquema)
         h1, h2 = n1 // 2 + 1, n2 // 2 + 1
-        tiles = 2 * ((h1 + 15) // 16)
+        tiles = 4 * ((h1 + 15) // 16)
         flop = (2.0 * n1 * h2 * h2 * 2 * (st[4] / max(st[0], 1)) / (tiles * h2)
                 + 2.0 * h1 * (st[3] / max(st[0], 1)) * h1 * 4) * n * nw
         out.append({"kernel": "prototype scheme: synth / detect_kernel<45,49>", "synth_ms": mean_s,

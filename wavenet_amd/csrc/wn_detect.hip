@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         }
     };
 
-    unsigned long long s1_units = 0;    // (row tile, column) pairs of stage 1 this wave computed (statistics)
+    unsigned long long s1_units = 0;    // (row tile, real or imaginary part, column) products of stage 1 this wave computed (statistics)
     unsigned long long redone = 0;      // windows done a second time, the whole way
     int next_off = 0;
     if (w < total) {
@@ -436,9 +436,10 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         floatx2 e4[TA];            // running sums of the squared A operands, per row-tile pair
         floatx2 sx[TA];            // running sums of the A operands (.x: the sum of the four samples)
         // Stage 1 comes in three cuts.  PILOT: the sum row tile 0 (rows a' < 16) of every column
-        // tile, from which the energy of each column tile is estimated.  WHOLE: every other row
-        // tile of every column tile.  ONE<c>: every other row tile of column tile c only, for
-        // windows whose energy the pilot finds in one column tile.
+        // tile, from which the energy of each column tile is estimated (real parts alone make
+        // the estimate too poor: four times as many windows had to be done twice).  WHOLE: every
+        // other row tile of every column tile.  ONE<c>: every other row tile of column tile c
+        // only, for windows whose energy the pilot finds in one column tile.
         constexpr int PILOT = 0, WHOLE = 1, ONE = 2;
         auto stage1 = [&](auto CUT_, auto CSEL_) {
             constexpr int CUT = decltype(CUT_)::value, CSEL = decltype(CSEL_)::value;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         };
 
         stage1(ic<PILOT>{}, ic<0>{});
-        s1_units += P::K2;
+        s1_units += 2 * P::K2;
         mfma_drain();
         // rough energy of each column tile (rows a' < 16 of it, mirrored pairs summed): where the
         // second stage starts, and whether one column tile holds nearly everything
@@ -646,10 +647,11 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             return e_half * 1.005f - seen * (1.f - 1e-5f) < lim_now;
         };
         constexpr int NCOL[3] = {16, C2T > 2 ? 16 : P::K2 - 16, P::K2 - 16 * (C2T - 1)};
-        constexpr int OTHER_TILES = T1 - 1;   // row tiles of stage 1 beside the pilot's
+        constexpr int OTHER_TILES = 2 * T1 - 2;   // (row tile, real or imaginary part) pairs of stage 1 beside the pilot's
 
         // ------------------------------------------------------------------ the rest of stage 1, stage 2
         auto after_stage1 = [&]() {
+            lap(ic<6>{});
             next_window_dma();
             lap(ic<2>{});
             mfma_drain();
@@ -804,9 +806,9 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         if (redone) atomicAdd(&stats[5], redone);
     }
     if constexpr (PROF) {
-        // out_bin[0..5]: clocks/256 per phase (DMA wait, stage 1, stores + next DMA issue,
-        // stage 2 with its arg-max work and checks, merge + decision, energies + tile order
-        // between the stages); [7]: total clocks/256; [8]: 100 MHz ticks/256
+        // out_bin[0..6]: clocks/256 per phase (DMA wait, pilot of stage 1 and the column tiles' rough
+        // energies, stores + next DMA issue, stage 2 with its arg-max work and checks, decision,
+        // energy of the window, rest of stage 1); [7]: total clocks/256; [8]: 100 MHz ticks/256
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             for (int i = 0; i < 7; ++i) out_bin[i] = (int)(prof[i] >> 8);
             out_bin[7] = (int)((__builtin_amdgcn_s_memtime() - prof_c0) >> 8);
