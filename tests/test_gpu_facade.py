@@ -93,6 +93,26 @@ def test_reference_quirks_are_kept(cs):
         c1_communication.escuchar_archivo("11:22:33:44:55:66")
 
 
+def test_frames_built_and_validated_in_batches(cs, golden):
+    """crear_tramas / validar_tramas: the frames of the golden vectors built by one launch equal the
+    ones built one by one, and the batch validation equals get_checksum_valido frame by frame."""
+    rng = np.random.default_rng(4)
+    payloads = [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in (0, 1, 19, 106, 107, 107, 64, 255)]
+    lote = cs.crear_tramas(1, MAC_O, MAC_D, 3, payloads)
+    uno = [cs.crear_trama(1, MAC_O, MAC_D, 3, p) for p in payloads]
+    assert [t.get_bytes() for t in lote] == [t.get_bytes() for t in uno]
+    assert [(t.version, t.tipo, t.length, bytes(t.payload), bytes(t.checksum)) for t in lote] == \
+        [(t.version, t.tipo, t.length, bytes(t.payload), bytes(t.checksum)) for t in uno]
+    assert cs.crear_tramas(1, MAC_O, MAC_D, 3, [b"hola"])[0].get_bytes().hex() == \
+        "01aabbccddeeff1122334455660304686f6c614b7b3be0"      # the reference's own frame for this input
+    lote[2].bytes_trama[20] ^= 1                     # a damaged payload byte
+    lote[5].checksum = bytearray(b"\0\0\0\0")        # a wrong stored checksum
+    assert cs.validar_tramas(lote) == [t.get_checksum_valido() for t in lote] == [True, True, False, True, True, False, True, True]
+    assert cs.crear_tramas(1, MAC_O, MAC_D, 3, []) == [] and cs.validar_tramas([]) == []
+    raro = cs.crear_tramas(1, b"\xaa", MAC_D, 3, [b"x", b"yy"])       # addresses of other lengths: the general path
+    assert [t.get_bytes() for t in raro] == [cs.crear_trama(1, b"\xaa", MAC_D, 3, p).get_bytes() for p in (b"x", b"yy")]
+
+
 def test_string_chunking(cs, golden):
     text = bytes.fromhex(golden["prueba_txt"])
     tramas = cs.obtener_tramas_desde_string(text, "aa:bb:cc:dd:ee:ff", "11:22:33:44:55:66")

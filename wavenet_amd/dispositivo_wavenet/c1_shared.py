@@ -212,6 +212,54 @@ def crear_trama(version, bytes_mac_org, bytes_mac_dest, tipo, cur_payload):
                  payload=cur_payload)
 
 
+def crear_tramas(version, bytes_mac_org, bytes_mac_dest, tipo, payloads):
+    """`crear_trama` for many payloads with the same header fields, all frames built and
+    checksummed by one kernel launch (a transfer then costs one launch for its frames instead
+    of one per frame).  Not in the reference, which builds frame by frame (c1_shared.py:484-490)."""
+    payloads = [bytes(p) for p in payloads]
+    if not payloads:
+        return []
+    if (len(bytes_mac_org) != 6 or len(bytes_mac_dest) != 6 or not 0 <= version <= 255 or not 0 <= tipo <= 255
+            or max(len(p) for p in payloads) > 255):
+        return [crear_trama(version, bytes_mac_org, bytes_mac_dest, tipo, p) for p in payloads]   # the general path
+    m = modem()
+    n, ancho = len(payloads), _ancho(max(len(p) for p in payloads))
+    campos = np.zeros((n, 16), dtype=np.uint8)
+    campos[:, :13] = np.frombuffer(bytes([version]) + bytes(bytes_mac_org) + bytes(bytes_mac_dest), dtype=np.uint8)
+    campos[:, 13] = tipo
+    carga = np.zeros((n, ancho), dtype=np.uint8)
+    for i, p in enumerate(payloads):
+        campos[i, 14] = len(p)
+        carga[i, :len(p)] = np.frombuffer(p, dtype=np.uint8)
+    frames, lens = m.build_frames(torch.from_numpy(campos).to(m.device), torch.from_numpy(carga).to(m.device), 288)
+    frames, lens = frames.cpu().numpy(), lens.cpu().numpy()
+    tramas = []
+    for i, p in enumerate(payloads):
+        t = Trama.__new__(Trama)
+        t.version, t.mac_origen, t.mac_destino, t.tipo, t.payload, t.length = version, bytes_mac_org, bytes_mac_dest, tipo, p, len(p)
+        t.bytes_trama = bytearray(frames[i, :lens[i]].tobytes())
+        t.checksum = t.bytes_trama[lens[i] - 4:lens[i]]
+        tramas.append(t)
+    return tramas
+
+
+def validar_tramas(tramas):
+    """`get_checksum_valido` of many frames by one kernel launch: a list of bools."""
+    tramas = list(tramas)
+    if not tramas:
+        return []
+    m = modem()
+    # what get_checksum_valido compares: the stored checksum with the CRC-32 of the first 15 + length bytes
+    filas = [bytes(t.bytes_trama[:15 + t.length]) for t in tramas]
+    ancho = _ancho(max(len(f) for f in filas))
+    datos = np.zeros((len(filas), ancho), dtype=np.uint8)
+    for i, f in enumerate(filas):
+        datos[i, :len(f)] = np.frombuffer(f, dtype=np.uint8)
+    lens = torch.tensor([len(f) for f in filas], dtype=torch.int32, device=m.device)
+    crc = m.crc32(torch.from_numpy(datos).to(m.device), lens).cpu().numpy()
+    return [bytes(t.checksum) == int(c).to_bytes(4, byteorder='big') for t, c in zip(tramas, crc)]
+
+
 def crear_trama_archivo_info(bytes_mac_org, bytes_mac_dest, cantidad_tramas, nombre_archivo):
     payload = cantidad_tramas.to_bytes(4, byteorder='big') + nombre_archivo.encode('utf-8')
     return crear_trama(VERSION, bytes_mac_org, bytes_mac_dest, TIPO_TRAMA_ARCHIVO_INFO, payload)
@@ -411,7 +459,7 @@ def cargar_wavs_en_canal(nombres, silencio=0.5):
 
 def _tramas_desde_bytes(data: bytes, mac_origen_str, mac_destino_str):
     org, dst = mac_str_to_bytes(mac_origen_str), mac_str_to_bytes(mac_destino_str)
-    return [crear_trama(VERSION, org, dst, TIPO_TRAMA_ARCHIVO, data[i:i + 107]) for i in range(0, len(data), 107)]
+    return crear_tramas(VERSION, org, dst, TIPO_TRAMA_ARCHIVO, [data[i:i + 107] for i in range(0, len(data), 107)])
 
 
 def obtener_tramas_desde_archivo(file_path, mac_origen_str, mac_destino_str):
