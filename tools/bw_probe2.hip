@@ -43,6 +43,22 @@ __global__ __launch_bounds__(T) void ptab(float4 *p, size_t n_items, size_t per_
         }
     }
 }
+// parts with non-temporal stores
+typedef float fx4 __attribute__((ext_vector_type(4)));
+template <int T>
+__global__ __launch_bounds__(T) void parts_nt(fx4 *p, size_t n_items, size_t per_item, float v) {
+    const fx4 val = {v, v, v, v};
+    for (size_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        fx4 *q = p + it * per_item;
+        for (size_t i = threadIdx.x; i < per_item; i += T) __builtin_nontemporal_store(val, q + i);
+    }
+}
+template <int T>
+__global__ __launch_bounds__(T) void chunk_nt(fx4 *p, size_t per_block, float v) {
+    const fx4 val = {v, v, v, v};
+    fx4 *q = p + (size_t)blockIdx.x * per_block;
+    for (size_t i = threadIdx.x; i < per_block; i += T) __builtin_nontemporal_store(val, q + i);
+}
 template <int T>
 __global__ __launch_bounds__(T) void stride(float4 *p, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < n; i += (size_t)gridDim.x * T) p[i] = make_float4(v, v, v, v);
@@ -76,6 +92,17 @@ int main(int argc, char **argv) {
     for (long kb : {192}) {
         const size_t per = (size_t)kb * 1024 / 16;
         for (long grid : {512, 1024, 2048}) time([&] { parts<512><<<(unsigned)grid, 512>>>(a, n / per, per, 1.f); }, "parts512", kb, grid);
+    }
+    for (long kb : {4, 16}) {
+        const size_t per = (size_t)kb * 1024 / 16;
+        time([&] { chunk_nt<256><<<(unsigned)(n / per), 256>>>((fx4 *)a, per, 1.f); }, "chunk-nt", kb, 0);
+    }
+    for (long kb : {192, 768}) {
+        const size_t per = (size_t)kb * 1024 / 16;
+        for (long grid : {512, 1024}) {
+            time([&] { parts<512><<<(unsigned)grid, 512>>>(a, n / per, per, 1.f); }, "parts512", kb, grid);
+            time([&] { parts_nt<512><<<(unsigned)grid, 512>>>((fx4 *)a, n / per, per, 1.f); }, "parts-nt", kb, grid);
+        }
     }
     float *tab;
     CK(hipMalloc(&tab, 256 * 4 * 896 * 4));

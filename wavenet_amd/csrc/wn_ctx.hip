@@ -304,7 +304,7 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
     }
     INIT_HIP(hipMalloc((void **)&ctx->d_stats, 8 * sizeof(unsigned long long)));
     INIT_HIP(hipMemset(ctx->d_stats, 0, 8 * sizeof(unsigned long long)));
-    if ((size_t)ctx->n * sizeof(double2) > 150 * 1024) {
+    if ((size_t)(ctx->n + n1 + n2) * sizeof(double2) > 150 * 1024) {
         wn_set_error("window length %d too large for the float64 phase table", ctx->n);
         wn_ctx_destroy(ctx);
         return WN_ERR_UNSUPPORTED;

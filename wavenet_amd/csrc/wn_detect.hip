@@ -829,12 +829,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ audio, long long n_streams,
                                                      long long stream_stride, long long first_sample,
-                                                     long long n_windows, int N,
+                                                     long long n_windows, int N, int n1, int n2, int e1, int e2,
                                                      const uint16_t *__restrict__ lut,
                                                      uint16_t *__restrict__ cls, float *__restrict__ mag,
                                                      int32_t *__restrict__ bin, unsigned long long *stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    double2 *tw = (double2 *)smem;  // N entries
+    double2 *tw = (double2 *)smem;            // N entries: exp(+2*pi*i*m/N)
+    double2 *c1 = tw + N, *c2 = c1 + n1;      // n1 and n2 entries: exp(-2*pi*i*m/n1), exp(-2*pi*i*m/n2)
+    double2 *Y = tw;                          // n1 * (n2/2+1) entries; the whole-spectrum path builds them over the table
+    bool small_ready = false;
     __shared__ double red[4][6];
     __shared__ double best_m[4];
     __shared__ int best_b[4];
@@ -848,15 +851,6 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
         const long long idx = base + tid;
         const int fl = idx < total ? (bin[idx] & FLAG_MASK) : 0;
         if (!__syncthreads_or(fl)) continue;
-        if (!table_ready) {
-            for (int m = tid; m < N; m += 256) {
-                double s, c;
-                sincospi(2.0 * (double)m / (double)N, &s, &c);
-                tw[m] = make_double2(c, s);
-            }
-            table_ready = true;
-            __syncthreads();
-        }
         // flagged windows of this chunk, one bit per thread
         const unsigned long long bal = __ballot(fl != 0);
         __syncthreads();
@@ -871,6 +865,16 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
             int rb;
             double rm;
             if (f & (FLAG_TOP2 | FLAG_TOP3)) {
+                if (!table_ready) {   // the same decision in every thread
+                    __syncthreads();
+                    for (int m = tid; m < N; m += 256) {
+                        double sn, cs;
+                        sincospi(2.0 * (double)m / (double)N, &sn, &cs);
+                        tw[m] = make_double2(cs, sn);
+                    }
+                    table_ready = true;
+                    __syncthreads();
+                }
                 const bool three = (f & FLAG_TOP3) != 0;
                 const int b1 = f & 0xFFFF, b2 = cls[wi], b3 = three ? __float_as_int(mag[wi]) : b1;
                 double r1 = 0, i1 = 0, r2 = 0, i2 = 0, r3 = 0, i3 = 0;
@@ -911,18 +915,53 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                 const bool any = __syncthreads_or(nz);
                 double bm = -1.0;
                 int bb = any ? 0x7fffffff : 0;
-                for (int b = tid; any && b < nbins; b += 256) {
-                    double re = 0, im = 0;
-                    int m = 0;
-                    for (int n = 0; n < N; ++n) {
-                        const double xv = (double)x[n];
-                        const double2 t = tw[m];
-                        re += xv * t.x; im += xv * t.y;
-                        m += b;
-                        m = m >= N ? m - N : m;
+                if (any) {
+                    // The whole spectrum in float64 by the same two-stage prime-factor DFT as the
+                    // float32 kernel, unfolded: Y[a][k2] = sum_b x[(n2*a + n1*b) mod N] * w2^(b*k2),
+                    // Z[k1][k2] = sum_a w1^(a*k1) * Y[a][k2] = X[(k1*e1 + k2*e2) mod N]; columns
+                    // k2 <= n2/2 hold every bin or its mirror image.  Y takes the place of the big
+                    // phase table, which is rebuilt when a later window needs it.
+                    const int K2 = n2 / 2 + 1;
+                    if (!small_ready) {
+                        for (int m = tid; m < n1 + n2; m += 256) {
+                            double sn, cs;
+                            sincospi(m < n1 ? 2.0 * (double)m / (double)n1 : 2.0 * (double)(m - n1) / (double)n2, &sn, &cs);
+                            c1[m] = make_double2(cs, -sn);
+                        }
+                        small_ready = true;
                     }
-                    const double mg = re * re + im * im;
-                    if (mg > bm) { bm = mg; bb = b; }  // b ascends: first maximum is kept
+                    __syncthreads();   // also: nobody reads the big table any more
+                    table_ready = false;
+                    for (int o = tid; o < n1 * K2; o += 256) {
+                        const int a = o / K2, k2 = o - a * K2;
+                        double re = 0, im = 0;
+                        int pos = (n2 * a) % N, m = 0;
+                        for (int bq = 0; bq < n2; ++bq) {
+                            const double xv = (double)x[pos];
+                            const double2 t = c2[m];
+                            re += xv * t.x; im += xv * t.y;
+                            pos += n1; pos = pos >= N ? pos - N : pos;
+                            m += k2; m = m >= n2 ? m - n2 : m;
+                        }
+                        Y[o] = make_double2(re, im);
+                    }
+                    __syncthreads();
+                    for (int o = tid; o < n1 * K2; o += 256) {
+                        const int k1 = o / K2, k2 = o - k1 * K2;
+                        double re = 0, im = 0;
+                        int m = 0;
+                        for (int a = 0; a < n1; ++a) {
+                            const double2 t = c1[m], y = Y[a * K2 + k2];
+                            re += t.x * y.x - t.y * y.y;
+                            im += t.x * y.y + t.y * y.x;
+                            m += k1; m = m >= n1 ? m - n1 : m;
+                        }
+                        const int kb = (int)(((long long)k1 * e1 + (long long)k2 * e2) % N);
+                        const int kk = kb < N - kb ? kb : N - kb;
+                        const double mg = re * re + im * im;
+                        if (kk < nbins && (mg > bm || (mg == bm && kk < bb))) { bm = mg; bb = kk; }   // first maximum wins
+                    }
+                    __syncthreads();   // Y is free again before the table is rebuilt over it
                 }
                 if (!any) bm = tid == 0 ? 0.0 : -1.0;
 #pragma unroll
@@ -1065,9 +1104,10 @@ static int detect_run(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int6
     long long blocks = (total + 255) / 256;
     const long long cap = (long long)ctx->num_cus * 4;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(refine_kernel, dim3((unsigned)blocks), dim3(256), (size_t)ctx->n * sizeof(double2), st,
-                       d_audio, (long long)n_streams, (long long)stream_stride, (long long)first_sample,
-                       (long long)n_windows, ctx->n, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats);
+    hipLaunchKernelGGL(refine_kernel, dim3((unsigned)blocks), dim3(256),
+                       (size_t)(ctx->n + ctx->n1 + ctx->n2) * sizeof(double2), st, d_audio, (long long)n_streams,
+                       (long long)stream_stride, (long long)first_sample, (long long)n_windows, ctx->n, ctx->n1, ctx->n2,
+                       ctx->e1, ctx->e2, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats);
     return wn_launch_check("refine_kernel");
 }
 
