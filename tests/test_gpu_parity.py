@@ -469,6 +469,42 @@ def test_detect_leaves_out_only_columns_that_cannot_matter(mb, golden):
     check_detect(mb, dc.astype(np.float32), 7055, lut)
 
 
+def test_detect_windows_done_twice(mb, golden):
+    """Windows with four fifths of their energy in one tile of spectrum columns, spread over many
+    bins, and the largest bin in another tile: the kernel starts them on the first tile alone, finds
+    that the rest cannot be ruled out, fetches the window again and does it the whole way.  Several streams at odd offsets, so that the second
+    fetch and the fetch of the next window are exercised at every alignment; bins, classes and
+    magnitudes must still be the oracle's."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    rng = np.random.default_rng(41)
+    t = np.arange(7055)
+    n_streams, n_windows, first = 3, 7, 5
+    stride = M.pad4(first + n_windows * 7055 + 9)
+    a = np.zeros((n_streams, stride), dtype=np.float32)
+    for s in range(n_streams):
+        for w in range(n_windows):
+            tile = (s + w) % 3
+            cols = np.arange(16 * tile, min(16 * tile + 16, 43))
+            bins = [k for k in range(60, 3500) if min(k % 85, 85 - k % 85) in cols]
+            chosen = rng.choice(bins, 40, replace=False)
+            x = sum(rng.uniform(0.5, 1.0) * np.cos(2 * np.pi * k * t / 7055 + rng.uniform(0, 6.28)) for k in chosen)
+            # ... and a fifth of the energy on one bin of another tile: the true maximum, outside the tile the kernel starts on
+            other = [k for k in range(60, 3500) if min(k % 85, 85 - k % 85) // 16 == (tile + 1) % 3]
+            x = x + 2.4 * np.cos(2 * np.pi * int(rng.choice(other)) * t / 7055 + 0.5)
+            if w % 3 == 2:
+                x = 0.45 * np.sin(2 * np.pi * (350 + 70 * (16 * s + w)) * t / 44100) * 40    # an ordinary tone in between
+            a[s, first + w * 7055:first + (w + 1) * 7055] = 0.01 * x
+    mb.detect_stats()
+    cls, mag, kbin = mb.detect(dev(a), n_streams, stride, n_windows, first)
+    st = mb.detect_stats(columns=True)
+    assert st[0] == n_streams * n_windows and st[5] >= 10          # most of the spread windows were done twice
+    for s in range(n_streams):
+        ob, om, oc = oracle_windows(a[s, first:first + n_windows * 7055], lut, 7055)
+        assert np.array_equal(kbin[s].cpu().numpy(), ob)
+        assert np.array_equal(cls[s].cpu().numpy().astype(np.uint16), oc)
+        assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
+
+
 def test_detect_refinement_paths_forced(golden):
     """Raise the tie band so that the float64 re-evaluation runs on ordinary windows: both
     the two-bin and the whole-spectrum path must reproduce the oracle."""
