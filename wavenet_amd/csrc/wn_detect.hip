@@ -162,6 +162,13 @@ __device__ __forceinline__ void mfma2_acc(floatx4 &acc, float a, float b_acc) {
 __device__ __forceinline__ void mfma2_new(floatx4 &acc, float a, float b_acc) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b_acc));
 }
+// the same with the A operand in an accumulation register (half of the stage-2 twiddles live there)
+__device__ __forceinline__ void mfma2a_acc(floatx4 &acc, float a_acc, float b_acc) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "a"(a_acc), "a"(b_acc));
+}
+__device__ __forceinline__ void mfma2a_new(floatx4 &acc, float a_acc, float b_acc) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "a"(a_acc), "a"(b_acc));
+}
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 // a value that lives in an accumulation register from here on
 __device__ __forceinline__ void acc_const(float &dst, float v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); }
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             if (ap > H1 || k1 > H1) t = make_float2(0.f, 0.f);
             if (ap == 0) t.x *= 0.5f;
             t1c[tt][s] = t.x;
-            t1s[tt][s] = t.y;
+            acc_const(t1s[tt][s], t.y);
         });
     });
     // stage-1 gather: A-operand row li of row tile t is a' = 16(t mod TA) + 4(li&3) + (li>>2),
@@ -440,6 +447,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // the estimate too poor: four times as many windows had to be done twice).  WHOLE: every
         // other row tile of every column tile.  ONE<c>: every other row tile of column tile c
         // only, for windows whose energy the pilot finds in one column tile.
+        // (Doing the k-steps in pairs, for half as many changes between matrix and vector work, was
+        // slower: 24 LDS reads in one go exceed the 15 the wave may have outstanding.)
         constexpr int PILOT = 0, WHOLE = 1, ONE = 2;
         auto stage1 = [&](auto CUT_, auto CSEL_) {
             constexpr int CUT = decltype(CUT_)::value, CSEL = decltype(CSEL_)::value;
@@ -583,13 +592,13 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     if constexpr (s == 0) {
                         mfma2_new(acc[tt][0], t1c[tt][s], Yr[c][tau][r]);
                         mfma2_new(acc[tt][2], t1c[tt][s], Yi[c][tau][r]);
-                        mfma2_new(acc[tt][1], t1s[tt][s], Yi[c][tau + TA][r]);
-                        mfma2_new(acc[tt][3], t1s[tt][s], Yr[c][tau + TA][r]);
+                        mfma2a_new(acc[tt][1], t1s[tt][s], Yi[c][tau + TA][r]);
+                        mfma2a_new(acc[tt][3], t1s[tt][s], Yr[c][tau + TA][r]);
                     } else {
                         mfma2_acc(acc[tt][0], t1c[tt][s], Yr[c][tau][r]);
                         mfma2_acc(acc[tt][2], t1c[tt][s], Yi[c][tau][r]);
-                        mfma2_acc(acc[tt][1], t1s[tt][s], Yi[c][tau + TA][r]);
-                        mfma2_acc(acc[tt][3], t1s[tt][s], Yr[c][tau + TA][r]);
+                        mfma2a_acc(acc[tt][1], t1s[tt][s], Yi[c][tau + TA][r]);
+                        mfma2a_acc(acc[tt][3], t1s[tt][s], Yr[c][tau + TA][r]);
                     }
                 });
             });
