@@ -427,6 +427,8 @@ def main():
                          "stage1_tile_columns_per_window": s1_tiles * (n2 // 2 + 1),
                          "windows_done_twice": st_redone / max(st_windows, 1),
                          "flop_per_window_whole_spectrum": detect_flop_per_window(n1, n2),
+                         "frac_if_priced_by_whole_spectrum": detect_flop_per_window(n1, n2) * win_per_launch
+                         / (det_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "note": "achieved counts the flop of what the kernel ran: the parts of both DFT stages it could "
                                  "not rule out by the energy bound (counted by the kernel); with "
                                  "the whole-spectrum figure per window the same time would read %.1f TFLOP/s"
