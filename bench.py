@@ -117,25 +117,22 @@ def cpu_baseline_all_cores(n_streams):
 
 
 def profile_traffic(kernel, units, units_key, suffix="_pmc.json"):
-    """(HBM bytes per launch, source text) of `kernel` from the newest committed counter summary
-    under profiles/ (by modification time), scaled from the units per launch recorded there to
-    `units`; (None, reason) when there is no summary, it lacks the kernel, or it does not record
-    its launch size."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), key=os.path.getmtime)
+    """(HBM bytes per launch, source text) of `kernel` from the committed counter summaries under
+    profiles/: the last one by name (tags are rNNx) that names the kernel and records the launch
+    size it was taken at, scaled from that size to `units`; (None, reason) when there is none."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), reverse=True)
     files = [f for f in files if suffix != "_pmc.json" or not f.endswith("_kernelbench_pmc.json")]
-    if not files:
-        return None, "no committed counter summary under profiles/"
-    path = files[-1]
-    with open(path) as f:
-        pmc = json.load(f)
-    k = pmc.get("kernels", {}).get(kernel, {})
-    base = pmc.get(units_key)
-    if "hbm_bytes" not in k or not base:
-        return None, "profiles/%s has no per-launch bytes of %s" % (os.path.basename(path), kernel)
-    return k["hbm_bytes"] * units / base, (
-        "from committed profile profiles/%s (rocprofv3 --pmc FETCH_SIZE, x2 for 16-byte streaming reads on gfx950, + "
-        "WRITE_SIZE passes of this command at commit %s), scaled by launch size %s/%s; not measured by this run"
-        % (os.path.basename(path), pmc.get("source_commit_or_parent", "?"), units, base))
+    for path in files:
+        with open(path) as f:
+            pmc = json.load(f)
+        k = pmc.get("kernels", {}).get(kernel, {})
+        base = pmc.get(units_key)
+        if "hbm_bytes" in k and base:
+            return k["hbm_bytes"] * units / base, (
+                "from committed profile profiles/%s (rocprofv3 --pmc FETCH_SIZE, x2 for 16-byte streaming reads on "
+                "gfx950, + WRITE_SIZE passes of this command at commit %s), scaled by launch size %s/%s; not measured "
+                "by this run" % (os.path.basename(path), pmc.get("source_commit_or_parent", "?"), units, base))
+    return None, "no committed counter summary under profiles/ has per-launch bytes and the launch size of " + kernel
 
 
 def timed_launches(fn, reps=3):
@@ -152,12 +149,12 @@ def timed_launches(fn, reps=3):
 
 
 def kernelbench_traffic(kernel):
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernelbench_pmc.json")), key=os.path.getmtime)
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        k = json.load(f).get("kernels", {}).get(kernel, {})
-    return k.get("hbm_bytes"), "profiles/" + os.path.basename(files[-1])
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernelbench_pmc.json")), reverse=True):
+        with open(path) as f:
+            k = json.load(f).get("kernels", {}).get(kernel, {})
+        if "hbm_bytes" in k:
+            return k["hbm_bytes"], "profiles/" + os.path.basename(path)
+    return None, None
 
 
 def side_measurements(m, audio, n_streams, stride, nwin):
