@@ -207,6 +207,9 @@ def parse_args(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="ranks may share a device (rank r uses device r mod device count): rehearsal of the "
                          "multi-rank branch on a box with fewer devices than ranks; needs --backend gloo")
+    ap.add_argument("--dist-alone", action="store_true",
+                    help="with one rank, still form the process group and run the record gather through it "
+                         "(exercises RCCL on a one-GPU box)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements after the timed steps (sync search, checksum batch)")
     ap.add_argument("--rank-info", action="store_true",
@@ -273,15 +276,25 @@ def main():
         raise SystemExit("bench.py: ranks sharing a device cannot form an RCCL communicator; use --backend gloo")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.dist_alone
+    if use_dist:
+        if world == 1:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                free_port = sk.getsockname()[1]
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
         # communicator set-up is not part of a step: run the collectives the steps use once,
         # on empty-sized data, before anything is timed (also when --warmup is 0)
-        SH.all_reduce_max(0.0, device)
-        SH.gather_records(torch.zeros((1, SH.RECORD_BYTES), dtype=torch.uint8, device=device), world, dst=0)
+        SH.all_reduce_max(0.0, device, even_alone=True)
+        SH.gather_records(torch.zeros((1, SH.RECORD_BYTES), dtype=torch.uint8, device=device), world, dst=0,
+                          even_alone=True)
         dist.barrier()
 
     m = M.Modem(M.esquema_b())
@@ -331,11 +344,11 @@ def main():
             outs.append((frames, lens, by.view(n, 128), ln.view(-1), rec, end.view(-1)))
         packed = SH.pack_records(torch.cat([o[2] for o in outs]), torch.cat([o[3] for o in outs]),
                                  torch.cat([o[4] for o in outs]))
-        gathered = SH.gather_records(packed, S * world, dst=0)
+        gathered = SH.gather_records(packed, S * world, dst=0, even_alone=use_dist)
         return outs, gathered
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -349,8 +362,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     counters = m.detect_stats(columns=True)
-    if world > 1:
-        elapsed = SH.all_reduce_max(elapsed, device)
+    if use_dist:
+        elapsed = SH.all_reduce_max(elapsed, device, even_alone=True)
 
     # correctness of what was timed: every stream's frame came back bit-exact and valid
     for frames, lens, by, ln, rec, end in outs:
@@ -359,7 +372,7 @@ def main():
         r = rec.cpu().numpy().view(M.REC_DTYPE).reshape(-1)
         assert (r["status"] == 0).all() and (r["crc_ok"] == 1).all()
     gathered_ok = None
-    if rank == 0 and world > 1:
+    if rank == 0 and use_dist:
         # the gathered records are every rank's frames in stream order: rank 0 rebuilds the frames
         # of all S * world streams from their indices (inputs are a function of the index) and compares
         assert gathered.shape == (S * world, SH.RECORD_BYTES)
@@ -407,7 +420,7 @@ def main():
                        "parallelism": "streams sharded by contiguous index blocks, gather of 140-B records"},
             "frames_per_s": world * S * args.steps / elapsed,
             "launcher": launcher, "devices_visible": n_dev,
-            "gather": None if world == 1 else {
+            "gather": None if not use_dist else {
                 "backend": "RCCL all-gather of %d-byte records on device tensors" % SH.RECORD_BYTES
                 if args.backend == "nccl" else "gloo all-gather, records staged through host memory",
                 "records": S * world, "verified_in_stream_order": gathered_ok,
@@ -448,7 +461,7 @@ def main():
                 "sample": "%d streams per core, one single-threaded process per core, %.1f s wall"
                           % (max(1, args.cpu_streams // 2), all_cores[2])}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -54,9 +54,9 @@ def _wire_device(t: torch.Tensor) -> torch.device:
     return t.device
 
 
-def all_reduce_max(value: float, device: torch.device) -> float:
+def all_reduce_max(value: float, device: torch.device, even_alone: bool = False) -> float:
     """Largest `value` over the ranks (the benchmark's max-over-ranks step time)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not even_alone):
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     t = t.to(_wire_device(t))
@@ -64,11 +64,13 @@ def all_reduce_max(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
-def gather_records(packed: torch.Tensor, n_total: int, dst: int = 0):
+def gather_records(packed: torch.Tensor, n_total: int, dst: int = 0, even_alone: bool = False):
     """Gathers every rank's packed records on rank `dst` in stream order.  Returns the
     [n_total,140] tensor there (on the device of `packed`) and None elsewhere.  Shards may
-    differ by one stream, so each rank pads to the largest shard and rank dst trims."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    differ by one stream, so each rank pads to the largest shard and rank dst trims.  A single
+    rank returns its records as they are, unless `even_alone` asks for the collective anyway
+    (the same code path on a communicator of one)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not even_alone):
         return packed
     world, rank = dist.get_world_size(), dist.get_rank()
     biggest = -(-n_total // world)
