@@ -505,6 +505,38 @@ def test_detect_windows_done_twice(mb, golden):
         assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
 
 
+@pytest.mark.parametrize("scheme", ["B", "A"])
+def test_detect_random_mixtures(mb, ma, golden, scheme):
+    """Windows drawn at random: up to four tones of log-uniform strengths on arbitrary (not
+    bin-centred) frequencies, a DC offset, a noise floor from nothing to louder than the tones,
+    sometimes silence in part of the window, any overall scale.  Whatever path a window takes
+    (one column tile, all of them, twice, float64 candidates, float64 spectrum), bin, class and
+    magnitude are the oracle's."""
+    m, n, lut = (mb, 7055, golden["classes_b_7055"]) if scheme == "B" else (ma, 2205, golden["classes_a_2205"])
+    lut = np.array(lut, dtype=np.uint16)
+    rng = np.random.default_rng(1234 if scheme == "B" else 4321)
+    t = np.arange(n)
+    wins = []
+    for i in range(400):
+        x = np.zeros(n)
+        for _ in range(int(rng.integers(0, 5))):
+            f = rng.uniform(0, 22050)
+            x += 10 ** rng.uniform(-3, 0) * np.sin(2 * np.pi * f * t / 44100 + rng.uniform(0, 6.28))
+        if rng.random() < 0.3:
+            x += rng.uniform(-0.5, 0.5)
+        if rng.random() < 0.7:
+            x += 10 ** rng.uniform(-5, 0) * rng.standard_normal(n)
+        if rng.random() < 0.2:
+            a, b = sorted(rng.integers(0, n, 2))
+            x[a:b] = 0.0
+        wins.append(x * 10 ** rng.uniform(-2, 1))
+    x32 = np.concatenate(wins).astype(np.float32)
+    m.detect_stats()
+    check_detect(m, x32, n, lut)
+    st = m.detect_stats(columns=True)
+    assert st[0] == 400 and st[3] < 400 * (43 if scheme == "B" else 25)   # some windows needed only part of the spectrum
+
+
 def test_detect_refinement_paths_forced(golden):
     """Raise the tie band so that the float64 re-evaluation runs on ordinary windows: both
     the two-bin and the whole-spectrum path must reproduce the oracle."""
