@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         floatx2 raw_p[TA], raw_m[TA], xs[TA], xd[TA];
         floatx2 e4[TA];            // running sums of the squared A operands, per row-tile pair
         floatx2 sx[TA];            // running sums of the A operands (.x: the sum of the four samples)
+        float keep_s[KS1], keep_d[KS1];   // A operands of the difference tile of pair 0, k-step by k-step
         // Stage 1 comes in three cuts.  PILOT: the sum row tile 0 (rows a' < 16) of every column
         // tile, from which the energy of each column tile is estimated (real parts alone make
         // the estimate too poor: four times as many windows had to be done twice).  WHOLE: every
@@ -452,11 +453,13 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         constexpr int PILOT = 0, WHOLE = 1, ONE = 2;
         auto stage1 = [&](auto CUT_, auto CSEL_) {
             constexpr int CUT = decltype(CUT_)::value, CSEL = decltype(CSEL_)::value;
-            constexpr int NP = CUT == PILOT ? 1 : TA;   // row-tile pairs gathered
+            // row-tile pairs gathered: the pilot takes pair 0 (and keeps the operands of its
+            // difference tile for the other cuts), the other cuts take the rest
+            constexpr int P0 = CUT == PILOT ? 0 : 1, NP = CUT == PILOT ? 1 : TA - 1;
             auto rd = [&](auto KS) {   // issue the sample reads of k-step KS
                 constexpr int ks = decltype(KS)::value;
                 static_for<NP>([&](auto PR) {
-                    constexpr int pr = decltype(PR)::value;
+                    constexpr int pr = P0 + decltype(PR)::value;
                     raw_p[pr][0] = *(const float *)(smem + ad_p[pr] + 4 * N1 * ks);
                     raw_m[pr][0] = *(const float *)(smem + ad_m[pr] + 4 * N1 * (KS1 - 1 - ks));
                     raw_p[pr][1] = *(const float *)(smem + ad_p[pr + TA] + 4 * N1 * ks);
@@ -466,11 +469,15 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             auto fold = [&](auto KS) {   // samples read last -> A operands of k-step KS: fold columns, then rows
                 constexpr int ks = decltype(KS)::value;
                 static_for<NP>([&](auto T) {
-                    constexpr int t = decltype(T)::value;
+                    constexpr int t = P0 + decltype(T)::value;
                     const floatx2 sab = raw_p[t] + raw_m[t], dab = raw_p[t] - raw_m[t];   // (sa, sb), (da, db)
                     xs[t] = pk_butterfly(sab);                                            // (sa + sb, sa - sb)
                     xd[t] = pk_butterfly(dab);
-                    if constexpr (CUT != PILOT) {
+                    if constexpr (CUT == PILOT) {
+                        keep_s[ks] = xs[t].y;
+                        keep_d[ks] = xd[t].y;
+                    }
+                    {
                         if constexpr (ks == 0) {
                             e4[t] = (xs[t] * xs[t] + xd[t] * xd[t]) * w_first;
                             sx[t] = xs[t] * w_first;
@@ -501,12 +508,15 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                         constexpr int c = decltype(C)::value, t = decltype(T)::value;
                         constexpr bool mine = CUT == PILOT ? t == 0 : (t != 0 && (CUT == WHOLE || c == CSEL));
                         if constexpr (mine) {
+                            // the difference tile of pair 0 takes the operands the pilot kept
+                            const float as = t == TA ? keep_s[ks] : xs[t % TA][t / TA];
+                            const float ad = t == TA ? keep_d[ks] : xd[t % TA][t / TA];
                             if constexpr (ks == 0) {
-                                mfma1_new(Yr[c][t], xs[t % TA][t / TA], t2c[ks][c]);
-                                mfma1_new(Yi[c][t], xd[t % TA][t / TA], t2s[ks][c]);
+                                mfma1_new(Yr[c][t], as, t2c[ks][c]);
+                                mfma1_new(Yi[c][t], ad, t2s[ks][c]);
                             } else {
-                                mfma1_acc(Yr[c][t], xs[t % TA][t / TA], t2c[ks][c]);
-                                mfma1_acc(Yi[c][t], xd[t % TA][t / TA], t2s[ks][c]);
+                                mfma1_acc(Yr[c][t], as, t2c[ks][c]);
+                                mfma1_acc(Yi[c][t], ad, t2s[ks][c]);
                             }
                         }
                     });
