@@ -51,21 +51,23 @@ WIN = 7055
 
 def detect_flop(n1: int, n2: int):
     """Algorithmic flop of the folded prime-factor DFT (multiply-adds of the matrix products
-    only, without tile padding) as (stage 1 per (row tile, column) product, stage 2 per spectrum
-    column).  Stage 1: for each of n1 rows, real and imaginary part of h2 columns from h2 folded
-    samples; its rows come in 2*ceil(h1/16) tiles (sums and differences of mirrored rows), and the
-    kernel counts the (row tile, real or imaginary part, column) products it computes.  Stage 2: four real sums over h1
-    folded rows for each of h1 output pairs of a column.  A window has h2 columns; the kernel
-    computes only what can still change the decision."""
+    only, without tile padding) per unit the kernel counts, as (stage-1 flop per unit, stage-1
+    units per window, stage-2 flop per unit, stage-2 units per window).  Stage 1: for each of n1
+    rows, real and imaginary part of h2 columns from h2 folded samples; its rows come in
+    2*ceil(h1/16) tiles (sums and differences of mirrored rows); unit = (row tile, real or
+    imaginary part, column).  Stage 2: four real sums over h1 folded rows for each of h1 output
+    pairs of a column, in ceil(h1/16) row tiles; unit = (row tile, column).  The kernel computes
+    only the units that can still change the decision."""
     h1, h2 = n1 // 2 + 1, n2 // 2 + 1
-    tiles = 2 * 2 * ((h1 + 15) // 16)      # row tiles of sums and of differences, real and imaginary part each
-    return 2.0 * n1 * h2 * h2 * 2 / (tiles * h2), 2.0 * h1 * h1 * 4, tiles
+    u1 = 2 * 2 * ((h1 + 15) // 16) * h2
+    u2 = ((h1 + 15) // 16) * h2
+    return 2.0 * n1 * h2 * h2 * 2 / u1, u1, 2.0 * h1 * h1 * 4 * h2 / u2, u2
 
 
 def detect_flop_per_window(n1: int, n2: int) -> float:
-    """The same with every column computed (the whole spectrum)."""
-    s1, s2, tiles = detect_flop(n1, n2)
-    return (s1 * tiles + s2) * (n2 // 2 + 1)
+    """The same with every unit computed (the whole spectrum)."""
+    f1, u1, f2, u2 = detect_flop(n1, n2)
+    return f1 * u1 + f2 * u2
 
 
 def make_inputs(n, first_index, device):
@@ -396,11 +398,11 @@ def main():
         win_per_launch = sub * nwin
         # flop of what the launches computed: stage 1 of every window, stage 2 of the spectrum
         # columns the kernel did not leave out (counted by the kernel itself over the timed steps)
-        st_windows, _, _, st_columns, st_units, st_redone = counters
-        s1_flop_per_unit, s2_flop_per_col, s1_tiles = detect_flop(n1, n2)
-        cols_per_window = st_columns / max(st_windows, 1)
+        st_windows, _, _, st_cells, st_units, st_redone = counters
+        s1_flop_per_unit, s1_units_full, s2_flop_per_unit, s2_units_full = detect_flop(n1, n2)
+        cells_per_window = st_cells / max(st_windows, 1)
         units_per_window = st_units / max(st_windows, 1)
-        flop = (s1_flop_per_unit * units_per_window + s2_flop_per_col * cols_per_window) * win_per_launch
+        flop = (s1_flop_per_unit * units_per_window + s2_flop_per_unit * cells_per_window) * win_per_launch
         achieved = flop / (det_ms * 1e-3) / 1e12
         # HBM traffic of a detection launch: not measurable from inside this process; taken from the
         # newest committed counter passes of this same command, only if they are of this kernel and
@@ -431,10 +433,10 @@ def main():
                          "traffic_source": traffic_source,
                          "flop_per_window": flop / win_per_launch, "windows_per_launch": win_per_launch,
                          "ms_per_launch": det_ms,
-                         "spectrum_columns_computed_per_window": cols_per_window,
-                         "spectrum_columns_per_window": n2 // 2 + 1,
+                         "stage2_tile_columns_computed_per_window": cells_per_window,
+                         "stage2_tile_columns_per_window": s2_units_full,
                          "stage1_tile_columns_computed_per_window": units_per_window,
-                         "stage1_tile_columns_per_window": s1_tiles * (n2 // 2 + 1),
+                         "stage1_tile_columns_per_window": s1_units_full,
                          "windows_done_twice": st_redone / max(st_windows, 1),
                          "flop_per_window_whole_spectrum": detect_flop_per_window(n1, n2),
                          "frac_if_priced_by_whole_spectrum": detect_flop_per_window(n1, n2) * win_per_launch

@@ -118,8 +118,9 @@ int wn_ctx_destroy(wn_ctx *ctx);
 int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
 /* Counters since the last call (synchronises `stream`): out[0] windows detected,
  * out[1] windows whose two or three candidate bins were re-evaluated in float64, out[2] windows
- * whose whole spectrum was; and how much of the two DFT stages the kernel computed: out[3] spectrum
- * columns (k mod n2, folded: (n2+1)/2 per window at most) whose second stage was computed,
+ * whose whole spectrum was; and how much of the two DFT stages the kernel computed: out[3] (row
+ * tile of 16 outputs, spectrum column) products of the second stage (((n1+1)/2 + 15)/16 tiles times
+ * (n2+1)/2 columns k mod n2, folded, per window at most),
  * out[4] (row tile of 16, real or imaginary part, column) products of the first stage
  * (((n1+1)/2 + 15)/16*2 tiles times 2 times (n2+1)/2 columns per window at most), out[5] windows that were started on one column tile and
  * had to be done again on all of them (their work is counted twice in out[3], out[4]).  The rest

@@ -15,4 +15,4 @@ for what, audio in (("clean", clean), ("noisy 0.1", clean + 0.1 * torch.randn_li
     m.detect(audio, S, stride, nwin); torch.cuda.synchronize(); m.detect_stats()
     e0.record(); m.detect(audio, S, stride, nwin); e1.record(); torch.cuda.synchronize()
     st = m.detect_stats(columns=True)
-    print(what, "ms %.3f" % e0.elapsed_time(e1), "cols/win %.2f units/win %.1f redone %.4f" % (st[3]/st[0], st[4]/st[0], st[5]/st[0]), st[:3])
+    print(what, "ms %.3f" % e0.elapsed_time(e1), "stage-2 units/win %.2f stage-1 units/win %.1f redone %.4f" % (st[3]/st[0], st[4]/st[0], st[5]/st[0]), st[:3])

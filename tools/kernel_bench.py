@@ -92,15 +92,15 @@ def main():
             n1, n2 = M.host_dft_plan(m.esquema)
             k2 = n2 // 2 + 1
             h1 = n1 // 2 + 1
-            cols = st[3] / max(st[0], 1)            # spectrum columns whose second stage was computed, per window
-            units = st[4] / max(st[0], 1)           # (row tile, column) products of the first stage, per window
-            tiles = 4 * ((h1 + 15) // 16)           # row tiles of sums / differences x real / imaginary part
-            flop = (2.0 * n1 * k2 * k2 * 2 * units / (tiles * k2) + 2.0 * h1 * cols * h1 * 4) * S * nwin
+            ta = (h1 + 15) // 16
+            cells = st[3] / max(st[0], 1)           # (row tile, column) products of the second stage, per window
+            units = st[4] / max(st[0], 1)           # (row tile, real/imaginary, column) products of the first stage
+            flop = (2.0 * n1 * k2 * k2 * 2 * units / (4 * ta * k2) + 2.0 * h1 * h1 * 4 * k2 * cells / (ta * k2)) * S * nwin
             out.append({"kernel": "detect_kernel<83,85>+refine", "bound": "mfma", "ms": mean, "ms_min": best,
                         "algorithmic_flop": flop, "achieved_TFLOPs": flop / mean / 1e9, "peak_TFLOPs": 157.3,
                         "frac": flop / mean / 1e9 / 157.3, "hbm_GBps": S * nwin * WIN * 4 / mean / 1e6,
-                        "units": "%d windows" % (S * nwin), "columns_computed_per_window": cols, "columns_per_window": k2,
-                        "stage1_tile_columns_computed_per_window": units, "stage1_tile_columns_per_window": tiles * k2,
+                        "units": "%d windows" % (S * nwin), "stage2_tile_columns_computed_per_window": cells, "stage2_tile_columns_per_window": ta * k2,
+                        "stage1_tile_columns_computed_per_window": units, "stage1_tile_columns_per_window": 4 * ta * k2,
                         "refined": st[:3]})
         del audio
 
@@ -180,13 +180,13 @@ def main():
         ok = bool(((cls[:, :msg] & 0x1FF).to(torch.uint8) == rows[:, :msg]).all())
         n1, n2 = M.host_dft_plan(ma.esquema)
         h1, h2 = n1 // 2 + 1, n2 // 2 + 1
-        tiles = 4 * ((h1 + 15) // 16)
-        flop = (2.0 * n1 * h2 * h2 * 2 * (st[4] / max(st[0], 1)) / (tiles * h2)
-                + 2.0 * h1 * (st[3] / max(st[0], 1)) * h1 * 4) * n * nw
+        ta = (h1 + 15) // 16
+        flop = (2.0 * n1 * h2 * h2 * 2 * (st[4] / max(st[0], 1)) / (4 * ta * h2)
+                + 2.0 * h1 * h1 * 4 * h2 * (st[3] / max(st[0], 1)) / (ta * h2)) * n * nw
         out.append({"kernel": "prototype scheme: synth / detect_kernel<45,49>", "synth_ms": mean_s,
                     "synth_GBps": n * stride_a * 4 / mean_s / 1e6, "detect_ms": mean_d,
                     "detect_TFLOPs": flop / mean_d / 1e9, "detect_frac_f32_mfma": flop / mean_d / 1e9 / 157.3,
-                    "windows": n * nw, "columns_computed_per_window": st[3] / max(st[0], 1), "columns_per_window": h2,
+                    "windows": n * nw, "stage2_tile_columns_computed_per_window": st[3] / max(st[0], 1), "stage2_tile_columns_per_window": ta * h2,
                     "bytes_exact": ok})
 
 

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     }
     const float w_first = lg == 0 ? 0.5f : 1.f;
     const float w_last = (KS1 - 1 + KS1 * lg) > H2 ? 0.f : 1.f;
-    unsigned long long cols_done = 0;   // columns k2 whose second stage this wave ran (statistics)
+    unsigned long long cells_done = 0;  // (row tile, column) products of stage 2 this wave computed (statistics)
     __syncthreads();
 
     // bins of this lane's outputs (tile, register, column tile, plus/minus side), kept in
@@ -592,71 +592,9 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
 
         Top3 best;
         float eproc;   // energy of the outputs this lane has looked at (each bin once)
-        auto col_tile = [&](auto C) {   // every output with k2 in column tile C
-            constexpr int c = decltype(C)::value;
-            floatx4 acc[TA][4];   // the sums A, B, C, E of each row tile
-            static_for<KS2>([&](auto S) {
-                constexpr int s = decltype(S)::value, tau = s >> 2, r = s & 3;
-                static_for<TA>([&](auto TT) {
-                    constexpr int tt = decltype(TT)::value;
-                    if constexpr (s == 0) {
-                        mfma2_new(acc[tt][0], t1c[tt][s], Yr[c][tau][r]);
-                        mfma2_new(acc[tt][2], t1c[tt][s], Yi[c][tau][r]);
-                        mfma2a_new(acc[tt][1], t1s[tt][s], Yi[c][tau + TA][r]);
-                        mfma2a_new(acc[tt][3], t1s[tt][s], Yr[c][tau + TA][r]);
-                    } else {
-                        mfma2_acc(acc[tt][0], t1c[tt][s], Yr[c][tau][r]);
-                        mfma2_acc(acc[tt][2], t1c[tt][s], Yi[c][tau][r]);
-                        mfma2a_acc(acc[tt][1], t1s[tt][s], Yi[c][tau + TA][r]);
-                        mfma2a_acc(acc[tt][3], t1s[tt][s], Yr[c][tau + TA][r]);
-                    }
-                });
-            });
-            mfma_drain();
-#pragma unroll
-            for (int tt = 0; tt < TA; ++tt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) after_drain(acc[tt][i]);
-            __builtin_amdgcn_sched_barrier(0);
-            // arg-max work of the column tile: two outputs per accumulator element; the float part
-            // on register pairs (packed f32 instructions), the keys one by one
-            floatx2 es_p = {0.f, 0.f}, es_m = {0.f, 0.f};
-            float dup_row0 = 0.f;
-            static_for<TA>([&](auto TT) {
-                static_for<2>([&](auto HALF) {
-                    constexpr int tt = decltype(TT)::value, hf = decltype(HALF)::value;
-                    const floatx2 A = hf ? acc[tt][0].hi : acc[tt][0].lo, B = hf ? acc[tt][1].hi : acc[tt][1].lo;
-                    const floatx2 Cc = hf ? acc[tt][2].hi : acc[tt][2].lo, E = hf ? acc[tt][3].hi : acc[tt][3].lo;
-                    const floatx2 rp = A + B, rm = A - B, ip = Cc - E, im = Cc + E;
-                    const floatx2 mp2 = rp * rp + ip * ip, mm2 = rm * rm + im * im;
-                    es_p += mp2;
-                    es_m += mm2;
-                    if constexpr (tt == 0 && hf == 0) dup_row0 = mm2.x;
-                    static_for<2>([&](auto EL) {
-                        constexpr int r = 2 * hf + decltype(EL)::value;
-                        float mp = mp2[decltype(EL)::value], mm = mm2[decltype(EL)::value];
-                        const unsigned tp = tag[tt][r][c][0], tm = tag[tt][r][c][1];
-                        // outputs that must not compete although their value is not zero: known positions
-                        constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
-                        if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
-                        if constexpr (c == 0 || (tt == 0 && r == 0) || (xhere && P::XMINUS))
-                            mm = __builtin_unpredictable(tm & EP_UNUSED) ? 0.f : mm;
-                        best.mx = max(best.mx, max(__float_as_uint(mp), __float_as_uint(mm)));
-                        top3_insert(best, (__float_as_uint(mp) & ~KEY_BIN) | tp);
-                        top3_insert(best, (__float_as_uint(mm) & ~KEY_BIN) | tm);
-                    });
-                });
-            });
-            // each bin once: where k2 = 0 (column tile 0, li = 0) every minus-side output repeats its
-            // plus side, and so does the one of row k1 = 0 (row tile 0, register 0, lane group 0)
-            float em = es_m.x + es_m.y;
-            if constexpr (c == 0) em = li == 0 ? 0.f : em - (lg == 0 ? dup_row0 : 0.f);
-            else em -= lg == 0 ? dup_row0 : 0.f;
-            eproc += (es_p.x + es_p.y) + em;
-        };
-        // Column tiles still to do cannot matter once everything outside the outputs already
-        // seen holds less energy than the smallest value that could still change the decision
-        // (`lim`, below).  The float32 energy of the outputs seen can exceed the exact one by
+        // What is still to do cannot matter once everything outside the outputs already seen
+        // holds less energy than the smallest value that could still change the decision (`lim`,
+        // below).  The float32 energy of the outputs seen can exceed the exact one by
         // 2B*sum|Z| + n*B^2 <= 2B*sqrt(n*E) < 0.005 E (B = 724u*sqrt(E), n < 3600 outputs).
         auto rest_cannot_matter = [&](unsigned &mx_out) {
             mx_out = lane63(wave_max63(best.mx));
@@ -666,6 +604,83 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             return e_half * 1.005f - seen * (1.f - 1e-5f) < lim_now;
         };
         constexpr int NCOL[3] = {16, C2T > 2 ? 16 : P::K2 - 16, P::K2 - 16 * (C2T - 1)};
+        unsigned mxu = 0u;
+        bool have_max = false;
+        // Stage 2 of column tile C, one row tile of 16 outputs k1 at a time (44 matrix instructions
+        // and the arg-max work of 8 outputs per lane), with the check after each: true as soon as
+        // the rest cannot matter.  `more` says whether other column tiles would follow (after the
+        // very last row tile of the window there is nothing left to rule out).  The last column
+        // tile starts with the last row tile: that is where the separator, ping and end tones are.
+        auto col_tile = [&](auto C, bool more) -> bool {
+            constexpr int c = decltype(C)::value;
+            bool done = false;
+            static_for<TA>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                constexpr int tt = c == C2T - 1 ? (i == 0 ? TA - 1 : i - 1) : i;
+                if (!done) {
+                    floatx4 acc[4];   // the sums A, B, C, E
+                    static_for<KS2>([&](auto S) {
+                        constexpr int s = decltype(S)::value, tau = s >> 2, r = s & 3;
+                        if constexpr (s == 0) {
+                            mfma2_new(acc[0], t1c[tt][s], Yr[c][tau][r]);
+                            mfma2_new(acc[2], t1c[tt][s], Yi[c][tau][r]);
+                            mfma2a_new(acc[1], t1s[tt][s], Yi[c][tau + TA][r]);
+                            mfma2a_new(acc[3], t1s[tt][s], Yr[c][tau + TA][r]);
+                        } else {
+                            mfma2_acc(acc[0], t1c[tt][s], Yr[c][tau][r]);
+                            mfma2_acc(acc[2], t1c[tt][s], Yi[c][tau][r]);
+                            mfma2a_acc(acc[1], t1s[tt][s], Yi[c][tau + TA][r]);
+                            mfma2a_acc(acc[3], t1s[tt][s], Yr[c][tau + TA][r]);
+                        }
+                    });
+                    mfma_drain();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) after_drain(acc[q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // arg-max work: two outputs per accumulator element; the float part on register
+                    // pairs (packed f32 instructions), the keys one by one
+                    floatx2 es_p = {0.f, 0.f}, es_m = {0.f, 0.f};
+                    float dup_row0 = 0.f;
+                    static_for<2>([&](auto HALF) {
+                        constexpr int hf = decltype(HALF)::value;
+                        const floatx2 A = hf ? acc[0].hi : acc[0].lo, B = hf ? acc[1].hi : acc[1].lo;
+                        const floatx2 Cc = hf ? acc[2].hi : acc[2].lo, E = hf ? acc[3].hi : acc[3].lo;
+                        const floatx2 rp = A + B, rm = A - B, ip = Cc - E, im = Cc + E;
+                        const floatx2 mp2 = rp * rp + ip * ip, mm2 = rm * rm + im * im;
+                        es_p += mp2;
+                        es_m += mm2;
+                        if constexpr (tt == 0 && hf == 0) dup_row0 = mm2.x;
+                        static_for<2>([&](auto EL) {
+                            constexpr int r = 2 * hf + decltype(EL)::value;
+                            float mp = mp2[decltype(EL)::value], mm = mm2[decltype(EL)::value];
+                            const unsigned tp = tag[tt][r][c][0], tm = tag[tt][r][c][1];
+                            // outputs that must not compete although their value is not zero: known positions
+                            constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
+                            if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
+                            if constexpr (c == 0 || (tt == 0 && r == 0) || (xhere && P::XMINUS))
+                                mm = __builtin_unpredictable(tm & EP_UNUSED) ? 0.f : mm;
+                            best.mx = max(best.mx, max(__float_as_uint(mp), __float_as_uint(mm)));
+                            top3_insert(best, (__float_as_uint(mp) & ~KEY_BIN) | tp);
+                            top3_insert(best, (__float_as_uint(mm) & ~KEY_BIN) | tm);
+                        });
+                    });
+                    // each bin once: where k2 = 0 (column tile 0, li = 0) every minus-side output repeats
+                    // its plus side, and so does the one of row k1 = 0 (row tile 0, register 0, lane group 0)
+                    float em = es_m.x + es_m.y;
+                    if constexpr (c == 0) em = li == 0 ? 0.f : em - (lg == 0 ? dup_row0 : 0.f);
+                    else em -= lg == 0 ? dup_row0 : 0.f;
+                    eproc += (es_p.x + es_p.y) + em;
+                    cells_done += NCOL[c];
+                    if (i + 1 < TA || more) {
+                        if (rest_cannot_matter(mxu)) {
+                            have_max = true;
+                            done = true;
+                        }
+                    }
+                }
+            });
+            return done;
+        };
         constexpr int OTHER_TILES = 2 * T1 - 2;   // (row tile, real or imaginary part) pairs of stage 1 beside the pilot's
 
         // ------------------------------------------------------------------ the rest of stage 1, stage 2
@@ -680,30 +695,26 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             best.mx = 0u;
             eproc = 0.f;
         };
-        unsigned mxu = 0u;
-        bool have_max = false;
         bool whole = !one_tile;
         if (one_tile) {
             // the pilot found the energy in one column tile: stage 1 and stage 2 of that tile only
+            bool done = false;
             if (c_first == 0) {
                 stage1(ic<ONE>{}, ic<0>{});
                 after_stage1();
-                col_tile(ic<0>{});
+                done = col_tile(ic<0>{}, true);
             } else if (c_first == 1) {
                 stage1(ic<ONE>{}, ic<1>{});
                 after_stage1();
-                col_tile(ic<1>{});
+                done = col_tile(ic<1>{}, true);
             } else if constexpr (C2T > 2) {
                 stage1(ic<ONE>{}, ic<2>{});
                 after_stage1();
-                col_tile(ic<2>{});
+                done = col_tile(ic<2>{}, true);
             }
             const int ncol = c_first == 0 ? NCOL[0] : (c_first == 1 ? NCOL[1] : NCOL[2]);
             s1_units += (unsigned)(OTHER_TILES * ncol);
-            cols_done += (unsigned)ncol;
-            if (rest_cannot_matter(mxu)) {
-                have_max = true;
-            } else {
+            if (!done) {
                 // Other column tiles are needed after all (energy in one column tile, but spread
                 // over many bins: rare).  The window's buffer is by now being overwritten by the
                 // next window: wait for that DMA, fetch this window again and do it the whole way
@@ -722,6 +733,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             stage1(ic<WHOLE>{}, ic<0>{});
             s1_units += OTHER_TILES * P::K2;
             after_stage1();
+            have_max = false;
             unsigned todo = (1u << C2T) - 1u;
 #pragma nounroll
             for (int i = 0; i < C2T; ++i) {
@@ -738,20 +750,12 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     c = (int)(key & 3u);
                 }
                 todo &= ~(1u << c);
-                if (c == 0) {
-                    col_tile(ic<0>{});
-                    cols_done += 16;
-                } else if (c == 1) {
-                    col_tile(ic<1>{});
-                    cols_done += NCOL[1];
-                } else {
-                    if constexpr (C2T > 2) col_tile(ic<2>{});
-                    cols_done += NCOL[2];
-                }
-                if (i + 1 < C2T && rest_cannot_matter(mxu)) {
-                    have_max = true;
-                    break;
-                }
+                const bool more = i + 1 < C2T;
+                bool done = false;
+                if (c == 0) done = col_tile(ic<0>{}, more);
+                else if (c == 1) done = col_tile(ic<1>{}, more);
+                else if constexpr (C2T > 2) done = col_tile(ic<2>{}, more);
+                if (done) break;
             }
         }
         lap(ic<3>{});
@@ -819,8 +823,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         w = wn;
     }
     flush();
-    if (lane == 0 && cols_done) {
-        atomicAdd(&stats[3], cols_done);
+    if (lane == 0 && cells_done) {
+        atomicAdd(&stats[3], cells_done);
         atomicAdd(&stats[4], s1_units);
         if (redone) atomicAdd(&stats[5], redone);
     }
