@@ -102,12 +102,11 @@ struct Plan {
     static constexpr int EXT = N1 * (KS1 - 1);
     static constexpr int NDW = (3 + N + EXT - SM + 63) / 64;
     static constexpr int XW = (SM + 64 * NDW + 3) & ~3;   // floats of LDS per wave
-    static constexpr int EP = TA * 4 * 64 * 8;            // uint32 entries of the output-bin table
     static_assert(16 * TA <= N1 && KS2 <= 4 * TA && C2T >= 2 && C2T <= 4 && N / 2 <= (int)KEY_BIN &&
                       256 * (NDW - 1) < 4096 && 4 * N1 * (KS1 - 1) < 65536,
                   "plan limits");
-    // LDS map (bytes): output-bin table, class table, then one window buffer per wave
-    static constexpr int OFF_LUT = EP * 4;
+    // LDS map (bytes): class table, then one window buffer per wave
+    static constexpr int OFF_LUT = 0;
     static constexpr int OFF_XW = OFF_LUT + (((N / 2) * 2 + 15) & ~15);
     static constexpr size_t LDS = (size_t)OFF_XW + (size_t)4 * XW * 4;
     // idempotents of the index map: bin of Z[j][k2] is (j*E1 + k2*E2) mod N
@@ -234,27 +233,10 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     constexpr int H1 = P::H1, H2 = P::H2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float *smf = (float *)smem;
-    uint32_t *ep = (uint32_t *)smem;                    // [TA][4][64][8]: folded bin of an output, bit 15 = unused
     uint16_t *lut_s = (uint16_t *)(smem + P::OFF_LUT);  // class word per bin
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < N / 2; i += 256) lut_s[i] = lut[i];
-    // Accumulator element (output tile t, register r, column tile c) of lane l holds the sums
-    // for k1 = 16t + 4(l>>4) + r, k2 = 16c + (l&15); from them come Z[k1][k2] (entry 2c) and
-    // Z[n1-k1][k2] (entry 2c+1).  The bin of Z[j][k2] is (j*E1 + k2*E2) mod N folded to
-    // [0, N/2].  Padding rows and columns (whose sums are exactly zero), the bin the
-    // reference never looks at, and the second copy of self-mirrored outputs (k1 = 0 or
-    // k2 = 0) are marked unused.
-    for (int i = threadIdx.x; i < P::EP; i += 256) {
-        const int sg = i & 1, c = (i >> 1) & 3, l = (i >> 3) & 63, r = (i >> 9) & 3, t = i >> 11;
-        const int k1 = 16 * t + 4 * (l >> 4) + r, k2 = 16 * c + (l & 15);
-        const int j = sg ? (N1 - k1) % N1 : k1;
-        const int kb = (int)(((long long)j * P::E1 + (long long)k2 * P::E2) % N);
-        const int kk = min(kb, N - kb);
-        const bool ok = (c < C2T) & (k1 <= H1) & (k2 <= H2) & (kk < N / 2) & (!sg | ((k1 != 0) & (k2 != 0)));
-        const bool pad = (c >= C2T) | (k1 > H1) | (k2 > H2);
-        ep[i] = ok ? (uint32_t)kk : (pad ? KEY_BIN : (EP_UNUSED | KEY_BIN));
-    }
 
     const int li = lane & 15;  // A row / B column / D column
     const int lg = lane >> 4;  // A,B k index / D row group
@@ -327,18 +309,30 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     unsigned long long cells_done = 0;  // (row tile, column) products of stage 2 this wave computed (statistics)
     __syncthreads();
 
-    // bins of this lane's outputs (tile, register, column tile, plus/minus side), kept in
-    // registers for the whole launch
+    // Bins of this lane's outputs (tile, register, column tile, plus/minus side), kept in
+    // registers for the whole launch.  Accumulator element (output tile t, register r, column
+    // tile c) of lane l holds the sums for k1 = 16t + 4(l>>4) + r, k2 = 16c + (l&15); from them
+    // come Z[k1][k2] (side 0) and Z[n1-k1][k2] (side 1).  The bin of Z[j][k2] is
+    // (j*E1 + k2*E2) mod N folded to [0, N/2].  Padding rows and columns (whose sums are
+    // exactly zero) carry the bin field alone; the bin the reference never looks at and the
+    // second copy of self-mirrored outputs (k1 = 0 or k2 = 0) are marked unused.
     unsigned tag[TA][4][C2T][2];
 #pragma unroll
     for (int t = 0; t < TA; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < C2T; ++c) {
-                tag[t][r][c][0] = ep[(((t * 4 + r) * 64 + lane) << 3) + 2 * c];
-                tag[t][r][c][1] = ep[(((t * 4 + r) * 64 + lane) << 3) + 2 * c + 1];
-            }
+            for (int c = 0; c < C2T; ++c)
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg) {
+                    const int k1 = 16 * t + 4 * lg + r, k2 = 16 * c + li;
+                    const int j = sg ? (N1 - k1) % N1 : k1;
+                    const int kb = (int)(((long long)j * P::E1 + (long long)k2 * P::E2) % N);
+                    const int kk = min(kb, N - kb);
+                    const bool ok = (k1 <= H1) & (k2 <= H2) & (kk < N / 2) & (!sg | ((k1 != 0) & (k2 != 0)));
+                    const bool pad = (k1 > H1) | (k2 > H2);
+                    tag[t][r][c][sg] = ok ? (unsigned)kk : (pad ? KEY_BIN : (EP_UNUSED | KEY_BIN));
+                }
 
     // ---- window staging by LDS-DMA
     auto fetch = [&](long long s, long long wi) {
