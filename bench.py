@@ -433,6 +433,9 @@ def main():
                          "traffic_source": traffic_source,
                          "flop_per_window": flop / win_per_launch, "windows_per_launch": win_per_launch,
                          "ms_per_launch": det_ms,
+                         "algorithmic_bytes": win_per_launch * (WIN * 4 + 10),
+                         "achieved_GBps": win_per_launch * (WIN * 4 + 10) / (det_ms * 1e-3) / 1e9,
+                         "hbm_frac": win_per_launch * (WIN * 4 + 10) / (det_ms * 1e-3) / 1e9 / 8000.0,
                          "stage2_tile_columns_computed_per_window": cells_per_window,
                          "stage2_tile_columns_per_window": s2_units_full,
                          "stage1_tile_columns_computed_per_window": units_per_window,
