@@ -11,8 +11,9 @@
 // 2 bytes (int16) per sample out, nothing but the ~1.5 KB segment table per frame in.
 //
 // Layout: one workgroup owns a contiguous part of one frame's samples, keeps the frame's
-// segment table and the quarter-wave table in LDS, finds its first segment once, and every
-// thread writes 4 consecutive samples per step from a one-period table of the segment's tone.
+// segment table in LDS (and the quarter-wave table too when the scheme's tones are short),
+// finds its first segment once, and every thread writes 4 consecutive samples per step from a
+// one-period table of the segment's tone.
 #include <stdlib.h>
 
 #include "wn_common.h"
@@ -109,8 +110,9 @@ __device__ __forceinline__ int tab_pos(int i) { return i ^ (((i >> 5) ^ (i >> 10
 #define SYN_OFF_TAB (SYN_OFF_PERIOD + SYN_MAX_SEGS * 2)
 
 // One workgroup owns a contiguous part of one frame's samples and goes through the segments
-// that overlap it.  LDS holds the quarter-wave table, the frame's segment table and two
-// buffers of one tone period each.  A tone of f Hz repeats every sr/gcd(f, sr) samples: the
+// that overlap it.  LDS holds the frame's segment table and two buffers of one tone period
+// each, and with TAB_LDS the quarter-wave table (otherwise that is read from global memory, which
+// only the building of a period table and the rare sample-by-sample paths do).  A tone of f Hz repeats every sr/gcd(f, sr) samples: the
 // period of the current segment's tone (plus three wrapped entries) sits in one buffer, the
 // next segment's is built from the quarter-wave table into the other before this segment is
 // written, so a segment costs one barrier, and the steady state issues no global loads at all
@@ -120,7 +122,7 @@ __device__ __forceinline__ int tab_pos(int i) { return i ^ (((i >> 5) ^ (i >> 10
 // aligned vector of a segment are written one by one.  Segments shorter than four periods (and
 // tones whose period does not fit a buffer) take their samples straight from the quarter-wave
 // table.
-template <typename T>
+template <typename T, bool TAB_LDS>
 __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
     const int32_t *__restrict__ seg_start, const uint16_t *__restrict__ seg_freq, const int32_t *__restrict__ n_segs,
     int seg_cap, long long n_frames, int parts, int part_len, const long long *__restrict__ dst_off,
@@ -130,17 +132,19 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
     int32_t *s_start = (int32_t *)smem;                        // SYN_MAX_SEGS + 1
     uint16_t *s_freq = (uint16_t *)(smem + SYN_OFF_FREQ);      // frequency mod sr
     uint16_t *s_period = (uint16_t *)(smem + SYN_OFF_PERIOD);  // period of the tone, 0 = no table
-    T *tab = (T *)(smem + SYN_OFF_TAB);                        // tab_entries (quarter + 1 rounded up to 32)
-    T *per = tab + tab_entries;                                // [2][SYN_MAX_STRIDE]
+    T *tab_s = (T *)(smem + SYN_OFF_TAB);                      // tab_entries (quarter + 1 rounded up to 32)
+    T *per = tab_s + (TAB_LDS ? tab_entries : 0);              // [2][SYN_MAX_STRIDE]
     const int tid = threadIdx.x;
-    for (int i = tid; i <= quarter; i += SYN_BLOCK) tab[tab_pos(i)] = g_tab[i];
+    if constexpr (TAB_LDS)
+        for (int i = tid; i <= quarter; i += SYN_BLOCK) tab_s[tab_pos(i)] = g_tab[i];
     const int sr = 4 * quarter, half = 2 * quarter;
     const float inv_sr = 1.0f / (float)sr;
     typedef typename Vec4<T>::type V4;
     auto sine = [&](int m) -> T {          // amp*sin(2*pi*m/sr), 0 <= m < sr
         const bool neg = m >= half;
         const int m2 = neg ? m - half : m;
-        const T v = tab[tab_pos(m2 > quarter ? half - m2 : m2)];
+        const int mq = m2 > quarter ? half - m2 : m2;
+        const T v = TAB_LDS ? tab_s[tab_pos(mq)] : g_tab[mq];
         return neg ? (T)(-v) : v;
     };
     auto build = [&](T *dst, int f, int period) {   // one period of the f-Hz tone and its first three samples again
@@ -370,9 +374,9 @@ extern "C" int wn_synth_layout(wn_ctx *ctx, const uint8_t *d_frames, const int32
 // the dynamic LDS of synth_kernel depends on the scheme's sample rate and is checked against
 // 150 KB at launch: allow that much once
 int wn_synth_device_setup(int) {
-    WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    150 * 1024));
-    WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)synth_kernel<int16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    150 * 1024));
     return WN_OK;
 }
@@ -390,11 +394,17 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     WN_REQUIRE_DEVICE(ctx);
     const size_t esz = fmt == WN_FMT_F32 ? 4 : 2;
     const size_t tab_entries = ((size_t)ctx->quarter + 1 + 31) & ~(size_t)31;
-    const size_t lds = SYN_OFF_TAB + (tab_entries + 2 * SYN_MAX_STRIDE) * esz;
+    // Tones of many periods are written from period tables built once per segment, and the
+    // quarter-wave table is read only to build those: it then stays in global memory and four
+    // workgroups fit a CU (measured on 122 GB: 5.9-6.0 TB/s against 5.7 with the table in LDS and
+    // two workgroups per CU; plain stores in the same pattern reach 6.3).  Schemes with short
+    // tones take every sample from the quarter-wave table and keep it in LDS.
+    const bool tab_lds = ctx->s.tone_n < 16 * SYN_BLOCK;
+    const size_t lds = SYN_OFF_TAB + ((tab_lds ? tab_entries : 0) + 2 * SYN_MAX_STRIDE) * esz;
     WN_REQUIRE(lds <= 150 * 1024, "sample_rate too large for the LDS sine table");
     // one launch = as many workgroups as stay resident, each looping over (frame, part) items
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > (tab_lds ? 2 : 4)) per_cu = tab_lds ? 2 : 4;
     if (per_cu < 1) per_cu = 1;
     if (const int v = ctx->synth_per_cu)
         if (v >= 1 && v <= 2048 / SYN_BLOCK && (size_t)v * lds <= 160 * 1024) per_cu = v;
@@ -415,17 +425,19 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     const long long items = n * parts;
     const long long blocks = items < resident ? items : resident;
     hipStream_t st = (hipStream_t)stream;
+#define WN_SYNTH_LAUNCH(T, TAB, TABLE)                                                                          \
+    hipLaunchKernelGGL((synth_kernel<T, TAB>), dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,      \
+                       d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,                \
+                       (const long long *)d_dst_off, (const long long *)d_fill_to, (T *)d_audio,                   \
+                       (long long)audio_len, (const T *)(TABLE), ctx->quarter, (int)tab_entries)
     if (fmt == WN_FMT_F32) {
-        hipLaunchKernelGGL(synth_kernel<float>, dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,
-                           d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,
-                           (const long long *)d_dst_off, (const long long *)d_fill_to, (float *)d_audio,
-                           (long long)audio_len, (const float *)ctx->d_sin_f32, ctx->quarter, (int)tab_entries);
+        if (tab_lds) WN_SYNTH_LAUNCH(float, true, ctx->d_sin_f32);
+        else WN_SYNTH_LAUNCH(float, false, ctx->d_sin_f32);
     } else {
-        hipLaunchKernelGGL(synth_kernel<int16_t>, dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,
-                           d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,
-                           (const long long *)d_dst_off, (const long long *)d_fill_to, (int16_t *)d_audio,
-                           (long long)audio_len, (const int16_t *)ctx->d_sin_i16, ctx->quarter, (int)tab_entries);
+        if (tab_lds) WN_SYNTH_LAUNCH(int16_t, true, ctx->d_sin_i16);
+        else WN_SYNTH_LAUNCH(int16_t, false, ctx->d_sin_i16);
     }
+#undef WN_SYNTH_LAUNCH
     return wn_launch_check("synth_kernel");
 }
 
