@@ -448,11 +448,11 @@ def main():
                                  "not rule out by the energy bound (counted by the kernel); with "
                                  "the whole-spectrum figure per window the same time would read %.1f TFLOP/s"
                                  % (detect_flop_per_window(n1, n2) * win_per_launch / (det_ms * 1e-3) / 1e12)},
-            "synth": {"bound": "hbm", "kernel": "synth_kernel<float>", "ms_per_launch": syn_ms,
+            "synth": {"bound": "hbm", "kernel": "synth_kernel<float, false>", "ms_per_launch": syn_ms,
                       "algorithmic_bytes": sub * stride * 4,
                       "achieved_GBps": sub * stride * 4 / (syn_ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
                       "frac": sub * stride * 4 / (syn_ms * 1e-3) / 1e9 / 8000.0,
-                      "traffic": profile_traffic("synth_kernel<float>", sub * stride, "samples_per_launch")[0]},
+                      "traffic": profile_traffic("synth_kernel<float, false>", sub * stride, "samples_per_launch")[0]},
         }
         line.update(extras)
         if args.cpu_streams > 0 and world == 1:

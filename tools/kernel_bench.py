@@ -74,7 +74,7 @@ def main():
         mean, best = timed(lambda: m.synth(lay, dst, audio, stride, fill), args.reps)
         by = S * stride * 4
         if "synth" in only:
-            out.append({"kernel": "synth_kernel<float>", "bound": "hbm", "ms": mean, "ms_min": best,
+            out.append({"kernel": "synth_kernel<float, false>", "bound": "hbm", "ms": mean, "ms_min": best,
                         "algorithmic_bytes": by, "achieved_GBps": by / mean / 1e6, "peak_GBps": 8000,
                         "frac": by / mean / 1e6 / 8000, "units": "%d streams x %d samples" % (S, stride)})
         if "sync" in only:
