@@ -362,6 +362,43 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         });
         return off;
     };
+    // The same transfer as single instructions, issued between the matrix instructions of the first
+    // stage-2 cell of a window (one per MFMA: the address work of a piece runs while the matrix
+    // pipe is busy).  prepare() issues the two pieces that need per-lane handling and keeps the
+    // scalar bases of the rest; piece(k) issues the k-th of the others.
+    constexpr int DMA_FULL = P::NV4 / 64, DMA_REM = P::NV4 % 64, DMA_PIECES = DMA_FULL + P::NDW - 1;
+    static_assert(DMA_PIECES <= 4 * KS2, "one piece per matrix instruction of a cell");
+    const float *nx_src = audio, *nx_ext = audio;
+    unsigned m0_keep = 0;
+    auto fetch_prepare = [&](long long s, long long wi) {
+        const long long g0 = s * stream_stride + first_sample + wi * (long long)N;
+        const int off = (int)(g0 & 3);
+        const float *x0 = audio + g0;
+        nx_src = x0 - off;
+        nx_ext = x0 + (P::SM + 64 - off - N);
+        if constexpr (DMA_REM > 0) {
+            if (lane < DMA_REM)
+                dma_group<1, 1024, true>(nx_src + 4 * lane + 256 * DMA_FULL,
+                                         __builtin_amdgcn_readfirstlane(lds_base + 1024u * DMA_FULL));
+        }
+        const int i0 = P::SM + lane - off;
+        dma_group<1, 256, false>(x0 + (i0 < N ? i0 : i0 - N), __builtin_amdgcn_readfirstlane(lds_base + 4u * P::SM));
+        m0_keep = wn_m0_get();
+        return off;
+    };
+    auto fetch_piece = [&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if constexpr (k < DMA_FULL) {
+            if constexpr (k % 4 == 0) wn_m0_set(__builtin_amdgcn_readfirstlane(lds_base + 4096u * (k / 4)));
+            dma_piece<1024 * (k % 4), true>(nx_src + 1024 * (k / 4), 16u * lane);
+        } else if constexpr (k < DMA_PIECES) {
+            constexpr int j = k - DMA_FULL;
+            if constexpr (j % 4 == 0)
+                wn_m0_set(__builtin_amdgcn_readfirstlane(lds_base + 4u * (P::SM + 64) + 1024u * (j / 4)));
+            dma_piece<256 * (j % 4), false>(nx_ext + 256 * (j / 4), 4u * lane);
+        }
+        if constexpr (k == DMA_PIECES - 1) wn_m0_set(m0_keep);
+    };
     // (stream, window) of the window in work and of the one after it, advanced without divisions
     const long long adv_s = wstep / n_windows, adv_w = wstep - adv_s * n_windows;
     long long cur_s = w / n_windows, cur_w = w - cur_s * n_windows;
@@ -605,8 +642,9 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // the rest cannot matter.  `more` says whether other column tiles would follow (after the
         // very last row tile of the window there is nothing left to rule out).  The last column
         // tile starts with the last row tile: that is where the separator, ping and end tones are.
-        auto col_tile = [&](auto C, bool more) -> bool {
+        auto col_tile = [&](auto C, bool more, auto DMA) -> bool {
             constexpr int c = decltype(C)::value;
+            constexpr bool dma = decltype(DMA)::value != 0;   // the first cell issues the next window's transfer
             bool done = false;
             static_for<TA>([&](auto I) {
                 constexpr int i = decltype(I)::value;
@@ -615,16 +653,27 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     floatx4 acc[4];   // the sums A, B, C, E
                     static_for<KS2>([&](auto S) {
                         constexpr int s = decltype(S)::value, tau = s >> 2, r = s & 3;
+                        auto piece = [&](auto Q) {
+                            if constexpr (dma && i == 0) fetch_piece(ic<4 * s + decltype(Q)::value>{});
+                        };
                         if constexpr (s == 0) {
                             mfma2_new(acc[0], t1c[tt][s], Yr[c][tau][r]);
+                            piece(ic<0>{});
                             mfma2_new(acc[2], t1c[tt][s], Yi[c][tau][r]);
+                            piece(ic<1>{});
                             mfma2a_new(acc[1], t1s[tt][s], Yi[c][tau + TA][r]);
+                            piece(ic<2>{});
                             mfma2a_new(acc[3], t1s[tt][s], Yr[c][tau + TA][r]);
+                            piece(ic<3>{});
                         } else {
                             mfma2_acc(acc[0], t1c[tt][s], Yr[c][tau][r]);
+                            piece(ic<0>{});
                             mfma2_acc(acc[2], t1c[tt][s], Yi[c][tau][r]);
+                            piece(ic<1>{});
                             mfma2a_acc(acc[1], t1s[tt][s], Yi[c][tau + TA][r]);
+                            piece(ic<2>{});
                             mfma2a_acc(acc[3], t1s[tt][s], Yr[c][tau + TA][r]);
+                            piece(ic<3>{});
                         }
                     });
                     mfma_drain();
@@ -678,9 +727,17 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         constexpr int OTHER_TILES = 2 * T1 - 2;   // (row tile, real or imaginary part) pairs of stage 1 beside the pilot's
 
         // ------------------------------------------------------------------ the rest of stage 1, stage 2
-        auto after_stage1 = [&]() {
+        auto after_stage1 = [&](auto SPLIT) {
             lap(ic<6>{});
-            next_window_dma();
+            if constexpr (decltype(SPLIT)::value) {
+                // the transfer goes out piece by piece inside the first stage-2 cell; a wave without
+                // a next window fetches this one again (the data is not used)
+                flush();
+                const bool nxt = wn < total;
+                next_off = fetch_prepare(nxt ? f_s : cur_s, nxt ? f_w : cur_w);
+            } else {
+                next_window_dma();
+            }
             lap(ic<2>{});
             mfma_drain();
             energies();
@@ -695,16 +752,16 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             bool done = false;
             if (c_first == 0) {
                 stage1(ic<ONE>{}, ic<0>{});
-                after_stage1();
-                done = col_tile(ic<0>{}, true);
+                after_stage1(ic<1>{});
+                done = col_tile(ic<0>{}, true, ic<1>{});
             } else if (c_first == 1) {
                 stage1(ic<ONE>{}, ic<1>{});
-                after_stage1();
-                done = col_tile(ic<1>{}, true);
+                after_stage1(ic<1>{});
+                done = col_tile(ic<1>{}, true, ic<1>{});
             } else if constexpr (C2T > 2) {
                 stage1(ic<ONE>{}, ic<2>{});
-                after_stage1();
-                done = col_tile(ic<2>{}, true);
+                after_stage1(ic<1>{});
+                done = col_tile(ic<2>{}, true, ic<1>{});
             }
             const int ncol = c_first == 0 ? NCOL[0] : (c_first == 1 ? NCOL[1] : NCOL[2]);
             s1_units += (unsigned)(OTHER_TILES * ncol);
@@ -726,7 +783,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             // among the rest each time it has to go on
             stage1(ic<WHOLE>{}, ic<0>{});
             s1_units += OTHER_TILES * P::K2;
-            after_stage1();
+            after_stage1(ic<0>{});
             have_max = false;
             unsigned todo = (1u << C2T) - 1u;
 #pragma nounroll
@@ -746,9 +803,9 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 todo &= ~(1u << c);
                 const bool more = i + 1 < C2T;
                 bool done = false;
-                if (c == 0) done = col_tile(ic<0>{}, more);
-                else if (c == 1) done = col_tile(ic<1>{}, more);
-                else if constexpr (C2T > 2) done = col_tile(ic<2>{}, more);
+                if (c == 0) done = col_tile(ic<0>{}, more, ic<0>{});
+                else if (c == 1) done = col_tile(ic<1>{}, more, ic<0>{});
+                else if constexpr (C2T > 2) done = col_tile(ic<2>{}, more, ic<0>{});
                 if (done) break;
             }
         }
@@ -817,6 +874,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         w = wn;
     }
     flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer into this workgroup's LDS is left in flight
     if (lane == 0 && cells_done) {
         atomicAdd(&stats[3], cells_done);
         atomicAdd(&stats[4], s1_units);

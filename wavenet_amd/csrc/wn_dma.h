@@ -35,3 +35,20 @@ __device__ __forceinline__ void dma_group(const float *p, unsigned lds) {
 #undef WN_DMA_ASM
 }
 
+// The same transfers one instruction at a time, for issuing them between other instructions:
+// the LDS base is set once per run of pieces (wn_m0_set), a piece adds its immediate offset to
+// both addresses, and the global address is a scalar base plus a per-lane byte offset.
+__device__ __forceinline__ unsigned wn_m0_get() {
+    unsigned v;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(v));
+    return v;
+}
+__device__ __forceinline__ void wn_m0_set(unsigned v) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(v) : "memory"); }
+template <int OFF, bool X4>
+__device__ __forceinline__ void dma_piece(const float *base, unsigned lane_bytes) {
+    static_assert(OFF >= 0 && OFF < 4096, "immediate offset");
+    if constexpr (X4)
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane_bytes), "s"(base), "n"(OFF) : "memory");
+    else
+        asm volatile("global_load_lds_dword %0, %1 offset:%2" ::"v"(lane_bytes), "s"(base), "n"(OFF) : "memory");
+}
