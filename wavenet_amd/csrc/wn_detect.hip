@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         floatx4 Yr[C2T][T1], Yi[C2T][T1];
         // samples and A operands as register pairs (row tile t, row tile t + TA), so that the
         // folds are packed f32 instructions: 4 per pair of row tiles instead of 8
-        floatx2 raw_p[TA], raw_m[TA], xs[TA], xd[TA];
+        floatx2 raw_p[2][TA], raw_m[2][TA], xs[TA], xd[TA];   // samples: two sets, for even and odd k-steps
         floatx2 e4[TA];            // running sums of the squared A operands, per row-tile pair
         floatx2 sx[TA];            // running sums of the A operands (.x: the sum of the four samples)
         float keep_s[KS1], keep_d[KS1];   // A operands of the difference tile of pair 0, k-step by k-step
@@ -479,6 +479,10 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // the estimate too poor: four times as many windows had to be done twice).  WHOLE: every
         // other row tile of every column tile.  ONE<c>: every other row tile of column tile c
         // only, for windows whose energy the pilot finds in one column tile.
+        // The sample reads of k-step ks+2 are issued one after each matrix instruction of k-step
+        // ks (an LDS instruction issues while the matrix pipe works on the one before it; the
+        // vector instructions of the folds do not), into the register set that the fold of
+        // k-step ks has already consumed.
         // (Doing the k-steps in pairs, for half as many changes between matrix and vector work, was
         // slower: 24 LDS reads in one go exceed the 15 the wave may have outstanding.)
         constexpr int PILOT = 0, WHOLE = 1, ONE = 2;
@@ -487,21 +491,23 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             // row-tile pairs gathered: the pilot takes pair 0 (and keeps the operands of its
             // difference tile for the other cuts), the other cuts take the rest
             constexpr int P0 = CUT == PILOT ? 0 : 1, NP = CUT == PILOT ? 1 : TA - 1;
-            auto rd = [&](auto KS) {   // issue the sample reads of k-step KS
-                constexpr int ks = decltype(KS)::value;
-                static_for<NP>([&](auto PR) {
-                    constexpr int pr = P0 + decltype(PR)::value;
-                    raw_p[pr][0] = *(const float *)(smem + ad_p[pr] + 4 * N1 * ks);
-                    raw_m[pr][0] = *(const float *)(smem + ad_m[pr] + 4 * N1 * (KS1 - 1 - ks));
-                    raw_p[pr][1] = *(const float *)(smem + ad_p[pr + TA] + 4 * N1 * ks);
-                    raw_m[pr][1] = *(const float *)(smem + ad_m[pr + TA] + 4 * N1 * (KS1 - 1 - ks));
-                });
+            auto rd1 = [&](auto KS, auto M) {   // issue sample read M (of 4*NP) of k-step KS
+                constexpr int ks = decltype(KS)::value, m = decltype(M)::value, pr = P0 + m / 4, q = m % 4;
+                if constexpr (ks < KS1 && m < 4 * NP) {
+                    if constexpr (q == 0) raw_p[ks & 1][pr][0] = *(const float *)(smem + ad_p[pr] + 4 * N1 * ks);
+                    if constexpr (q == 1) raw_m[ks & 1][pr][0] = *(const float *)(smem + ad_m[pr] + 4 * N1 * (KS1 - 1 - ks));
+                    if constexpr (q == 2) raw_p[ks & 1][pr][1] = *(const float *)(smem + ad_p[pr + TA] + 4 * N1 * ks);
+                    if constexpr (q == 3) raw_m[ks & 1][pr][1] = *(const float *)(smem + ad_m[pr + TA] + 4 * N1 * (KS1 - 1 - ks));
+                }
             };
-            auto fold = [&](auto KS) {   // samples read last -> A operands of k-step KS: fold columns, then rows
+            auto rd = [&](auto KS) {   // all sample reads of k-step KS
+                static_for<4 * NP>([&](auto M) { rd1(KS, M); });
+            };
+            auto fold = [&](auto KS) {   // samples of k-step KS -> its A operands: fold columns, then rows
                 constexpr int ks = decltype(KS)::value;
                 static_for<NP>([&](auto T) {
                     constexpr int t = P0 + decltype(T)::value;
-                    const floatx2 sab = raw_p[t] + raw_m[t], dab = raw_p[t] - raw_m[t];   // (sa, sb), (da, db)
+                    const floatx2 sab = raw_p[ks & 1][t] + raw_m[ks & 1][t], dab = raw_p[ks & 1][t] - raw_m[ks & 1][t];   // (sa, sb), (da, db)
                     xs[t] = pk_butterfly(sab);                                            // (sa + sb, sa - sb)
                     xd[t] = pk_butterfly(dab);
                     if constexpr (CUT == PILOT) {
@@ -538,28 +544,28 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     static_for<T1>([&](auto T) {
                         constexpr int c = decltype(C)::value, t = decltype(T)::value;
                         constexpr bool mine = CUT == PILOT ? t == 0 : (t != 0 && (CUT == WHOLE || c == CSEL));
+                        // position of this pair of matrix instructions in the k-step
+                        constexpr int idx = CUT == PILOT ? c : (CUT == ONE ? t - 1 : c * (T1 - 1) + t - 1);
                         if constexpr (mine) {
                             // the difference tile of pair 0 takes the operands the pilot kept
                             const float as = t == TA ? keep_s[ks] : xs[t % TA][t / TA];
                             const float ad = t == TA ? keep_d[ks] : xd[t % TA][t / TA];
-                            if constexpr (ks == 0) {
-                                mfma1_new(Yr[c][t], as, t2c[ks][c]);
-                                mfma1_new(Yi[c][t], ad, t2s[ks][c]);
-                            } else {
-                                mfma1_acc(Yr[c][t], as, t2c[ks][c]);
-                                mfma1_acc(Yi[c][t], ad, t2s[ks][c]);
-                            }
+                            if constexpr (ks == 0) mfma1_new(Yr[c][t], as, t2c[ks][c]);
+                            else mfma1_acc(Yr[c][t], as, t2c[ks][c]);
+                            rd1(ic<ks + 2>{}, ic<2 * idx>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (ks == 0) mfma1_new(Yi[c][t], ad, t2s[ks][c]);
+                            else mfma1_acc(Yi[c][t], ad, t2s[ks][c]);
+                            rd1(ic<ks + 2>{}, ic<2 * idx + 1>{});
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     });
                 });
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ks + 1 < KS1) {
-                    fold(ic<ks + 1>{});                        // operands of k-step ks+1 (read before this k-step's MFMAs)
+                    fold(ic<ks + 1>{});                        // operands of k-step ks+1
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (ks + 2 < KS1)
-                        rd(ic<ks + 2>{});
-                    else
-                        asm volatile("s_nop 1" ::: "memory");   // operands just written, read by the next MFMA
+                    asm volatile("s_nop 1" ::: "memory");      // operands just written, read by the next MFMA
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
