@@ -41,6 +41,18 @@
 // the next window is fetched while stage 2 runs.
 // Bound: matrix cores (f32 MFMA, 64 FLOP/clk/SIMD).
 //
+// Only the part of the spectrum that can matter is computed.  By Parseval the outputs not yet
+// seen hold at most E - sum|Z seen|^2 (E from the samples); once that is below what could still
+// change the decision, the rest of both stages is left out and bins, classes, flags and
+// magnitudes are still those of the whole spectrum.  Stage 1 starts with a pilot (one row tile
+// of every column tile) that says where the energy is: a window with nearly all of it in one
+// column tile gets stage 1 and stage 2 of that tile only, cell by cell (row tile x column
+// tile) with the check after each; other windows get all of stage 1 and stage 2 in the order
+// of the pilot's energies.  A window that fails the check after a one-tile pass is done again
+// the whole way.  LDS and global-memory instructions issue beside the wave's matrix
+// instructions (vector-ALU ones do not), so sample reads and the next window's DMA pieces are
+// placed one after each MFMA.
+//
 // Decisions must equal the reference's float64 FFT.  The per-lane running top three are
 // kept as integer keys (|Z|^2 bits with the low 12 bits replaced by the bin), and the kernel
 // sums |Z|^2 over all its outputs: by Parseval that is the energy of the window, and the
