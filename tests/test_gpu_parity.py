@@ -188,6 +188,36 @@ def test_synth_tones_with_long_periods(plan):
     assert np.array_equal(w.cpu().numpy()[0, :int(n[0])], mo.wav_int16(frames[0], sch))
 
 
+def test_synth_sines_computed_on_the_gpu_equal_the_host_table(monkeypatch):
+    """Scheme B's synthesis computes the sines of its period tables in float64 on the GPU; schemes
+    with short tones (and WN_SYNTH_TABLE=lds) look them up in the quarter-wave table the host
+    built.  A ping tone of 1 Hz walks through every entry of that table (phase m = sample index,
+    21 168 samples live, 13 230 in the WAV variant, table 11 026 entries): both ways must give the
+    same float32 and the same int16 samples, and both must be the oracle's."""
+    import dataclasses
+    esq = dataclasses.replace(M.esquema_b(), ping_freq=1)
+    sch = dataclasses.replace(SB, ping_freq=1)
+    frames = [mo.build_frame(1, MAC_O, MAC_D, 3, bytes([0, 255, 3, 3, 17, 200]))]
+    buf, lens = rows_from(frames, 32)
+    ref = mo.emit_frame(frames[0], sch)
+    stride = M.pad4(len(ref) + 9)
+    got = {}
+    for mode in ("computed", "lds"):
+        if mode == "lds":
+            monkeypatch.setenv("WN_SYNTH_TABLE", "lds")
+        else:
+            monkeypatch.delenv("WN_SYNTH_TABLE", raising=False)
+        m = M.Modem(esq)
+        audio, n = m.encode_streams(dev(buf), dev(lens), stride)
+        wav, nw = m.encode_streams(dev(buf), dev(lens), stride, variant=L.EMIT_WAV, dtype=torch.int16)
+        got[mode] = (audio.cpu().numpy()[0, :int(n[0])], wav.cpu().numpy()[0, :int(nw[0])])
+    assert np.array_equal(got["computed"][0], got["lds"][0])
+    assert np.array_equal(got["computed"][1], got["lds"][1])
+    half_ulp = 0.5 * np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    assert np.all(np.abs(got["computed"][0].astype(np.float64) - ref) <= half_ulp * 1.0001 + 5e-11)
+    assert np.array_equal(got["computed"][1], mo.wav_int16(frames[0], sch))
+
+
 def test_synth_sample_counts_with_repeats(mb, golden):
     frames = [bytes.fromhex(c["frame"]) for c in golden["sample_counts_b"]]
     buf, lens = rows_from(frames, 128)

@@ -29,6 +29,7 @@ struct wn_ctx {
     // (WN_DETECT_PROFILE, WN_SYNTH_PER_CU, WN_SYNTH_PART); 0 = not set
     int detect_profile;
     int synth_per_cu;
+    int synth_table_lds;   // 1: keep the quarter-wave table in LDS whatever the scheme (WN_SYNTH_TABLE=lds)
     long long synth_part;
 };
 

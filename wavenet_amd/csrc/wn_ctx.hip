@@ -311,6 +311,7 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
     }
     if (const char *e = getenv("WN_DETECT_PROFILE")) ctx->detect_profile = atoi(e) != 0;
     if (const char *e = getenv("WN_SYNTH_PER_CU")) ctx->synth_per_cu = atoi(e);
+    if (const char *e = getenv("WN_SYNTH_TABLE")) ctx->synth_table_lds = e[0] == 'l';
     if (const char *e = getenv("WN_SYNTH_PART")) ctx->synth_part = atoll(e);
     {
         // everything that is per device and process-wide happens here, once, under a lock:

@@ -111,8 +111,8 @@ __device__ __forceinline__ int tab_pos(int i) { return i ^ (((i >> 5) ^ (i >> 10
 
 // One workgroup owns a contiguous part of one frame's samples and goes through the segments
 // that overlap it.  LDS holds the frame's segment table and two buffers of one tone period
-// each, and with TAB_LDS the quarter-wave table (otherwise that is read from global memory, which
-// only the building of a period table and the rare sample-by-sample paths do).  A tone of f Hz repeats every sr/gcd(f, sr) samples: the
+// each, and with TAB_LDS the quarter-wave table (otherwise a sine is computed in float64 where it
+// is needed, which only the building of a period table and the rare sample-by-sample paths do).  A tone of f Hz repeats every sr/gcd(f, sr) samples: the
 // period of the current segment's tone (plus three wrapped entries) sits in one buffer, the
 // next segment's is built from the quarter-wave table into the other before this segment is
 // written, so a segment costs one barrier, and the steady state issues no global loads at all
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
     const int32_t *__restrict__ seg_start, const uint16_t *__restrict__ seg_freq, const int32_t *__restrict__ n_segs,
     int seg_cap, long long n_frames, int parts, int part_len, const long long *__restrict__ dst_off,
     const long long *__restrict__ fill_to, T *__restrict__ audio, long long audio_len,
-    const T *__restrict__ g_tab, int quarter, int tab_entries) {
+    const T *__restrict__ g_tab, int quarter, int tab_entries, double amp, double gain) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int32_t *s_start = (int32_t *)smem;                        // SYN_MAX_SEGS + 1
     uint16_t *s_freq = (uint16_t *)(smem + SYN_OFF_FREQ);      // frequency mod sr
@@ -144,7 +144,22 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
         const bool neg = m >= half;
         const int m2 = neg ? m - half : m;
         const int mq = m2 > quarter ? half - m2 : m2;
-        const T v = TAB_LDS ? tab_s[tab_pos(mq)] : g_tab[mq];
+        T v;
+        if constexpr (TAB_LDS) {
+            v = tab_s[tab_pos(mq)];
+        } else {
+            const double sn = (mq == quarter) ? 1.0 : sin(2.0 * M_PI * (double)mq / (double)sr);
+            if constexpr (sizeof(T) == 4) {
+                double w = amp * sn;
+                if (gain != 1.0) {
+                    w = w * gain;
+                    w = w < -1.0 ? -1.0 : (w > 1.0 ? 1.0 : w);
+                }
+                v = (T)w;
+            } else {
+                v = (T)(amp * sn * 32767.0);
+            }
+        }
         return neg ? (T)(-v) : v;
     };
     auto build = [&](T *dst, int f, int period) {   // one period of the f-Hz tone and its first three samples again
@@ -394,12 +409,15 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     WN_REQUIRE_DEVICE(ctx);
     const size_t esz = fmt == WN_FMT_F32 ? 4 : 2;
     const size_t tab_entries = ((size_t)ctx->quarter + 1 + 31) & ~(size_t)31;
-    // Tones of many periods are written from period tables built once per segment, and the
-    // quarter-wave table is read only to build those: it then stays in global memory and four
-    // workgroups fit a CU (measured on 122 GB: 5.9-6.0 TB/s against 5.7 with the table in LDS and
-    // two workgroups per CU; plain stores in the same pattern reach 6.3).  Schemes with short
-    // tones take every sample from the quarter-wave table and keep it in LDS.
-    const bool tab_lds = ctx->s.tone_n < 16 * SYN_BLOCK;
+    // Tones of many periods are written from period tables built once per segment, and sines are
+    // needed only to build those (two per thread and segment at most): they are then computed
+    // where they are needed, by the expression the host table is built from, LDS holds no
+    // quarter-wave table and four workgroups fit a CU.  Measured on 122 GB: 6.0 TB/s; with the
+    // table read from global memory 5.7 (every load waits for the stores issued before it), with
+    // the table in LDS and two workgroups per CU 5.7; plain stores in the same pattern reach 6.3.
+    // Schemes with short tones take every sample from the quarter-wave table and keep it in LDS
+    // (WN_SYNTH_TABLE=lds forces that for any scheme: the two must give the same samples).
+    const bool tab_lds = ctx->s.tone_n < 16 * SYN_BLOCK || ctx->synth_table_lds;
     const size_t lds = SYN_OFF_TAB + ((tab_lds ? tab_entries : 0) + 2 * SYN_MAX_STRIDE) * esz;
     WN_REQUIRE(lds <= 150 * 1024, "sample_rate too large for the LDS sine table");
     // one launch = as many workgroups as stay resident, each looping over (frame, part) items
@@ -429,7 +447,7 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     hipLaunchKernelGGL((synth_kernel<T, TAB>), dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,      \
                        d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,                \
                        (const long long *)d_dst_off, (const long long *)d_fill_to, (T *)d_audio,                   \
-                       (long long)audio_len, (const T *)(TABLE), ctx->quarter, (int)tab_entries)
+                       (long long)audio_len, (const T *)(TABLE), ctx->quarter, (int)tab_entries, ctx->s.amp, ctx->s.gain)
     if (fmt == WN_FMT_F32) {
         if (tab_lds) WN_SYNTH_LAUNCH(float, true, ctx->d_sin_f32);
         else WN_SYNTH_LAUNCH(float, false, ctx->d_sin_f32);
