@@ -911,8 +911,13 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
-// float64 re-evaluation of flagged windows.  X[b] = sum_n x[n] * exp(-2*pi*i*((b*n) mod N)/N)
-// with the phase table built by sincospi in LDS the first time a workgroup needs it.
+// float64 re-evaluation of flagged windows, in two passes over the flags.
+// Pass 0: windows with two or three candidate bins, X[b] = sum_n x[n] * exp(2*pi*i*((b*n) mod N)/N)
+// by direct summation, the phase factor of m = 128*k + j taken as the product of two table
+// entries (128 + N/128 of them, built by sincospi: the LDS of a workgroup stays small and eight
+// workgroups share a CU); and windows flagged for the whole spectrum that turn out to be all
+// zeros (digital silence: np.argmax of zeros is 0).  Pass 1: the whole spectrum of the windows
+// still flagged, by the two-stage prime-factor DFT in float64 with Y in LDS.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -920,6 +925,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+template <int PASS>
 __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ audio, long long n_streams,
                                                      long long stream_stride, long long first_sample,
                                                      long long n_windows, int N, int n1, int n2, int e1, int e2,
@@ -927,22 +933,44 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                                                      uint16_t *__restrict__ cls, float *__restrict__ mag,
                                                      int32_t *__restrict__ bin, unsigned long long *stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    double2 *tw = (double2 *)smem;            // N entries: exp(+2*pi*i*m/N)
-    double2 *c1 = tw + N, *c2 = c1 + n1;      // n1 and n2 entries: exp(-2*pi*i*m/n1), exp(-2*pi*i*m/n2)
-    double2 *Y = tw;                          // n1 * (n2/2+1) entries; the whole-spectrum path builds them over the table
-    bool small_ready = false;
+    // pass 0: exp(2*pi*i*j/N), j < 128, then exp(2*pi*i*128*k/N), k < ceil(N/128)
+    double2 *tab_lo = (double2 *)smem, *tab_hi = tab_lo + 128;
+    // pass 1: Y, n1 * (n2/2+1) entries, then exp(-2*pi*i*m/n1), m < n1, and exp(-2*pi*i*m/n2), m < n2
+    double2 *Y = (double2 *)smem;
+    double2 *c1 = Y + n1 * (n2 / 2 + 1), *c2 = c1 + n1;
     __shared__ double red[4][6];
     __shared__ double best_m[4];
     __shared__ int best_b[4];
     __shared__ unsigned long long flagged[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long total = n_streams * n_windows;
-    bool table_ready = false;
     const int nbins = N / 2;
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&stats[0], (unsigned long long)total);
+    if constexpr (PASS == 0) {
+        if (blockIdx.x == 0 && tid == 0) atomicAdd(&stats[0], (unsigned long long)total);
+        double sn, cs;
+        if (tid < 128) {
+            sincospi(2.0 * (double)tid / (double)N, &sn, &cs);
+            tab_lo[tid] = make_double2(cs, sn);
+        } else if (128 * (tid - 128) < N) {
+            sincospi(2.0 * (double)(128 * (tid - 128)) / (double)N, &sn, &cs);
+            tab_hi[tid - 128] = make_double2(cs, sn);
+        }
+    } else {
+        for (int m = tid; m < n1 + n2; m += 256) {
+            double sn, cs;
+            sincospi(m < n1 ? 2.0 * (double)m / (double)n1 : 2.0 * (double)(m - n1) / (double)n2, &sn, &cs);
+            c1[m] = make_double2(cs, -sn);
+        }
+    }
+    __syncthreads();
+    auto phase = [&](unsigned m) {   // exp(2*pi*i*m/N), m < N
+        const double2 h = tab_hi[m >> 7], l = tab_lo[m & 127];
+        return make_double2(h.x * l.x - h.y * l.y, h.x * l.y + h.y * l.x);
+    };
     for (long long base = (long long)blockIdx.x * 256; base < total; base += (long long)gridDim.x * 256) {
         const long long idx = base + tid;
-        const int fl = idx < total ? (bin[idx] & FLAG_MASK) : 0;
+        int fl = idx < total ? (bin[idx] & FLAG_MASK) : 0;
+        if constexpr (PASS == 1) fl &= FLAG_FULL;
         if (!__syncthreads_or(fl)) continue;
         // flagged windows of this chunk, one bit per thread
         const unsigned long long bal = __ballot(fl != 0);
@@ -958,27 +986,18 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
             int rb;
             double rm;
             if (f & (FLAG_TOP2 | FLAG_TOP3)) {
-                if (!table_ready) {   // the same decision in every thread
-                    __syncthreads();
-                    for (int m = tid; m < N; m += 256) {
-                        double sn, cs;
-                        sincospi(2.0 * (double)m / (double)N, &sn, &cs);
-                        tw[m] = make_double2(cs, sn);
-                    }
-                    table_ready = true;
-                    __syncthreads();
-                }
+                if constexpr (PASS == 1) continue;
                 const bool three = (f & FLAG_TOP3) != 0;
                 const int b1 = f & 0xFFFF, b2 = cls[wi], b3 = three ? __float_as_int(mag[wi]) : b1;
                 double r1 = 0, i1 = 0, r2 = 0, i2 = 0, r3 = 0, i3 = 0;
                 for (int n = tid; n < N; n += 256) {
                     const double xv = (double)x[n];
-                    const double2 t1 = tw[(unsigned)(b1 * n) % (unsigned)N];
-                    const double2 t2 = tw[(unsigned)(b2 * n) % (unsigned)N];
+                    const double2 t1 = phase((unsigned)(b1 * n) % (unsigned)N);
+                    const double2 t2 = phase((unsigned)(b2 * n) % (unsigned)N);
                     r1 += xv * t1.x; i1 += xv * t1.y;
                     r2 += xv * t2.x; i2 += xv * t2.y;
                     if (three) {
-                        const double2 t3 = tw[(unsigned)(b3 * n) % (unsigned)N];
+                        const double2 t3 = phase((unsigned)(b3 * n) % (unsigned)N);
                         r3 += xv * t3.x; i3 += xv * t3.y;
                     }
                 }
@@ -1006,25 +1025,16 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                 bool nz = false;
                 for (int n = tid; n < N; n += 256) nz |= (x[n] != 0.0f);
                 const bool any = __syncthreads_or(nz);
+                if (PASS == 0 && any) continue;   // pass 1 does this window
                 double bm = -1.0;
                 int bb = any ? 0x7fffffff : 0;
                 if (any) {
                     // The whole spectrum in float64 by the same two-stage prime-factor DFT as the
                     // float32 kernel, unfolded: Y[a][k2] = sum_b x[(n2*a + n1*b) mod N] * w2^(b*k2),
                     // Z[k1][k2] = sum_a w1^(a*k1) * Y[a][k2] = X[(k1*e1 + k2*e2) mod N]; columns
-                    // k2 <= n2/2 hold every bin or its mirror image.  Y takes the place of the big
-                    // phase table, which is rebuilt when a later window needs it.
+                    // k2 <= n2/2 hold every bin or its mirror image.
                     const int K2 = n2 / 2 + 1;
-                    if (!small_ready) {
-                        for (int m = tid; m < n1 + n2; m += 256) {
-                            double sn, cs;
-                            sincospi(m < n1 ? 2.0 * (double)m / (double)n1 : 2.0 * (double)(m - n1) / (double)n2, &sn, &cs);
-                            c1[m] = make_double2(cs, -sn);
-                        }
-                        small_ready = true;
-                    }
-                    __syncthreads();   // also: nobody reads the big table any more
-                    table_ready = false;
+                    __syncthreads();   // nobody reads the previous window's Y any more
                     for (int o = tid; o < n1 * K2; o += 256) {
                         const int a = o / K2, k2 = o - a * K2;
                         double re = 0, im = 0;
@@ -1054,7 +1064,6 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                         const double mg = re * re + im * im;
                         if (kk < nbins && (mg > bm || (mg == bm && kk < bb))) { bm = mg; bb = kk; }   // first maximum wins
                     }
-                    __syncthreads();   // Y is free again before the table is rebuilt over it
                 }
                 if (!any) bm = tid == 0 ? 0.0 : -1.0;
 #pragma unroll
@@ -1155,9 +1164,9 @@ int wn_detect_device_setup(int device) {
     int rc = detect_attr<83, 85>();
     if (rc == WN_OK) rc = detect_attr<45, 49>();
     if (rc != WN_OK) return rc;
-    // the float64 phase table of the re-evaluation kernel lives in dynamic LDS: window length x 16
-    // bytes (wn_scheme_init refuses windows whose table would not fit)
-    WN_HIP_TRY(hipFuncSetAttribute((const void *)refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    // the whole-spectrum pass of the re-evaluation keeps its first-stage results in dynamic LDS:
+    // n1 * (n2/2 + 1) + n1 + n2 entries of 16 bytes (wn_scheme_init refuses windows that need more)
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)refine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    150 * 1024));
     // called with `device` current: the address of this device's copy of the workspace
     void *p = nullptr;
@@ -1194,11 +1203,17 @@ static int detect_run(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int6
     }
     if (rc != WN_OK) return rc;
     const long long total = n_streams * n_windows;
-    long long blocks = (total + 255) / 256;
-    const long long cap = (long long)ctx->num_cus * 4;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(refine_kernel, dim3((unsigned)blocks), dim3(256),
-                       (size_t)(ctx->n + ctx->n1 + ctx->n2) * sizeof(double2), st, d_audio, (long long)n_streams,
+    const long long chunks = (total + 255) / 256;
+    const long long b0 = chunks < (long long)ctx->num_cus * 8 ? chunks : (long long)ctx->num_cus * 8;
+    const long long b1 = chunks < (long long)ctx->num_cus * 2 ? chunks : (long long)ctx->num_cus * 2;
+    const size_t lds0 = (size_t)(128 + (ctx->n + 127) / 128) * sizeof(double2);
+    const size_t lds1 = (size_t)(ctx->n1 * (ctx->n2 / 2 + 1) + ctx->n1 + ctx->n2) * sizeof(double2);
+    hipLaunchKernelGGL(refine_kernel<0>, dim3((unsigned)b0), dim3(256), lds0, st, d_audio, (long long)n_streams,
+                       (long long)stream_stride, (long long)first_sample, (long long)n_windows, ctx->n, ctx->n1, ctx->n2,
+                       ctx->e1, ctx->e2, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats);
+    rc = wn_launch_check("refine_kernel<0>");
+    if (rc != WN_OK) return rc;
+    hipLaunchKernelGGL(refine_kernel<1>, dim3((unsigned)b1), dim3(256), lds1, st, d_audio, (long long)n_streams,
                        (long long)stream_stride, (long long)first_sample, (long long)n_windows, ctx->n, ctx->n1, ctx->n2,
                        ctx->e1, ctx->e2, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats);
     return wn_launch_check("refine_kernel");
