@@ -43,10 +43,19 @@ __device__ __forceinline__ unsigned wn_m0_get() {
     asm volatile("s_mov_b32 %0, m0" : "=s"(v));
     return v;
 }
-__device__ __forceinline__ void wn_m0_set(unsigned v) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(v) : "memory"); }
+__device__ __forceinline__ void wn_m0_set(unsigned v) {
+    v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);   // the same in every lane; no cost when already scalar
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(v) : "memory");
+}
 template <int OFF, bool X4>
 __device__ __forceinline__ void dma_piece(const float *base, unsigned lane_bytes) {
     static_assert(OFF >= 0 && OFF < 4096, "immediate offset");
+    // the base is the same in every lane; said so here, because the instruction needs it in scalar
+    // registers whatever the compiler has concluded about it (no cost when it already is there)
+    const unsigned long long bv = (unsigned long long)(uintptr_t)base;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bv);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bv >> 32));
+    base = (const float *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
     if constexpr (X4)
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane_bytes), "s"(base), "n"(OFF) : "memory");
     else
