@@ -194,9 +194,11 @@ __device__ __forceinline__ floatx2 pk_butterfly(floatx2 v) {
     return r;
 }
 
+// the DPP-selected lane's value where the row mask writes, 0 elsewhere (0 is neutral for the
+// unsigned maxima and key merges it feeds, and lets the move fold into the instruction using it)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ unsigned dpp_u(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xF, false);
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false);
 }
 
 // the DPP-selected lane's value where the row mask writes, 0 elsewhere
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             // wave-wide merge of the per-lane top three, all by DPP: lane pairs, quads, eights and
             // sixteens merge two disjoint lane sets each and leave every lane of a row with the
             // row's result; two row broadcasts then collect the four rows in the last row (the
-            // other rows merge with themselves and are not used).  Lane 63 decides and stores.
+            // other rows merge with zeros and are not used).  Lane 63 decides and stores.
             auto merge_with = [&](unsigned o1, unsigned o2, unsigned o3) {
                 top3_insert(best, o1);
                 top3_insert(best, o2);
