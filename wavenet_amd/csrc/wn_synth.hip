@@ -104,6 +104,33 @@ __device__ __forceinline__ int mod_sr(unsigned x, int sr, float inv_sr) {
 // low five bits are XOR-ed with the next two groups of five (a bijection inside each 32-entry row).
 __device__ __forceinline__ int tab_pos(int i) { return i ^ (((i >> 5) ^ (i >> 10)) & 31); }
 
+// sin(2*pi*m/sr) for 0 <= m <= quarter = sr/4, w = 2*pi/sr, in float64 by the power series on
+// [0, pi/4] (the sine of m or the cosine of quarter - m, whichever argument is the smaller):
+// within a few units of the last place, which a test compares entry by entry, after rounding
+// to the output format, with the table the host builds with sin().
+__device__ __forceinline__ double sin_quarter(int m, int quarter, double w) {
+    const bool upper = 2 * m > quarter;
+    const double x = w * (double)(upper ? quarter - m : m), z = x * x;
+    double s = -1.0 / 1307674368000.0;                      // sine: -x^15/15! ... -x^3/3!
+    s = fma(s, z, 1.0 / 6227020800.0);
+    s = fma(s, z, -1.0 / 39916800.0);
+    s = fma(s, z, 1.0 / 362880.0);
+    s = fma(s, z, -1.0 / 5040.0);
+    s = fma(s, z, 1.0 / 120.0);
+    s = fma(s, z, -1.0 / 6.0);
+    s = fma(x * z, s, x);
+    double c = 1.0 / 20922789888000.0;                      // cosine: x^16/16! ... -x^2/2!
+    c = fma(c, z, -1.0 / 87178291200.0);
+    c = fma(c, z, 1.0 / 479001600.0);
+    c = fma(c, z, -1.0 / 3628800.0);
+    c = fma(c, z, 1.0 / 40320.0);
+    c = fma(c, z, -1.0 / 720.0);
+    c = fma(c, z, 1.0 / 24.0);
+    c = fma(c, z, -0.5);
+    c = fma(c, z, 1.0);
+    return upper ? c : s;
+}
+
 #define SYN_MAX_STRIDE 2304  // longest tone period kept as a table: 2301 samples + 3 wrapped entries
 #define SYN_OFF_FREQ (((SYN_MAX_SEGS + 1) * 4 + 15) & ~15)
 #define SYN_OFF_PERIOD (SYN_OFF_FREQ + SYN_MAX_SEGS * 2)
@@ -127,7 +154,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
     const int32_t *__restrict__ seg_start, const uint16_t *__restrict__ seg_freq, const int32_t *__restrict__ n_segs,
     int seg_cap, long long n_frames, int parts, int part_len, const long long *__restrict__ dst_off,
     const long long *__restrict__ fill_to, T *__restrict__ audio, long long audio_len,
-    const T *__restrict__ g_tab, int quarter, int tab_entries, double amp, double gain) {
+    const T *__restrict__ g_tab, int quarter, int tab_entries, double amp, double gain, double w_unit) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int32_t *s_start = (int32_t *)smem;                        // SYN_MAX_SEGS + 1
     uint16_t *s_freq = (uint16_t *)(smem + SYN_OFF_FREQ);      // frequency mod sr
@@ -148,7 +175,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
         if constexpr (TAB_LDS) {
             v = tab_s[tab_pos(mq)];
         } else {
-            const double sn = (mq == quarter) ? 1.0 : sin(2.0 * M_PI * (double)mq / (double)sr);
+            const double sn = sin_quarter(mq, quarter, w_unit);
             if constexpr (sizeof(T) == 4) {
                 double w = amp * sn;
                 if (gain != 1.0) {
@@ -411,7 +438,7 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     const size_t tab_entries = ((size_t)ctx->quarter + 1 + 31) & ~(size_t)31;
     // Tones of many periods are written from period tables built once per segment, and sines are
     // needed only to build those (two per thread and segment at most): they are then computed
-    // where they are needed, by the expression the host table is built from, LDS holds no
+    // where they are needed (sin_quarter), LDS holds no
     // quarter-wave table and four workgroups fit a CU.  Measured on 122 GB: 6.0 TB/s; with the
     // table read from global memory 5.7 (every load waits for the stores issued before it), with
     // the table in LDS and two workgroups per CU 5.7; plain stores in the same pattern reach 6.3.
@@ -447,7 +474,7 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     hipLaunchKernelGGL((synth_kernel<T, TAB>), dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,      \
                        d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,                \
                        (const long long *)d_dst_off, (const long long *)d_fill_to, (T *)d_audio,                   \
-                       (long long)audio_len, (const T *)(TABLE), ctx->quarter, (int)tab_entries, ctx->s.amp, ctx->s.gain)
+                       (long long)audio_len, (const T *)(TABLE), ctx->quarter, (int)tab_entries, ctx->s.amp, ctx->s.gain, 2.0 * M_PI / (double)ctx->s.sample_rate)
     if (fmt == WN_FMT_F32) {
         if (tab_lds) WN_SYNTH_LAUNCH(float, true, ctx->d_sin_f32);
         else WN_SYNTH_LAUNCH(float, false, ctx->d_sin_f32);
