@@ -454,13 +454,13 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     if (const int v = ctx->synth_per_cu)
         if (v >= 1 && v <= 2048 / SYN_BLOCK && (size_t)v * lds <= 160 * 1024) per_cu = v;
     const long long resident = (long long)ctx->num_cus * per_cu;
-    // Large parts amortise the per-part set-up (segment table, first tone): 192 Ki samples
-    // (768 KB) when there is enough work for every resident workgroup four times over, smaller
-    // ones (down to 16 Ki) when there are few frames.  Measured on 122 GB of output: 5.7-6.1
-    // TB/s for parts of 192 Ki..4 Mi samples and 1-3 workgroups per CU, 5.1 TB/s at 48 Ki.
+    // Large parts amortise the per-part set-up (segment table, first tone): up to 768 Ki samples
+    // (3 MB) when there is enough work for every resident workgroup four times over, smaller ones
+    // (down to 16 Ki) when there are few frames.  Measured on 122 GB, sines computed in the kernel:
+    // 22.5 ms at 48 Ki, 20.6 at 96 Ki, 20.0 at 192 Ki, 19.8 at 384 Ki, 19.7 at 768 Ki and 1.5 Mi.
     // WN_SYNTH_PART / WN_SYNTH_PER_CU override the choice for tuning.
     long long part_want = (n * slot_len / (resident * 4) + 4095) & ~4095ll;
-    part_want = part_want < 16384 ? 16384 : (part_want > 196608 ? 196608 : part_want);
+    part_want = part_want < 16384 ? 16384 : (part_want > 786432 ? 786432 : part_want);
     if (ctx->synth_part >= 4096) part_want = ctx->synth_part;
     long long parts = (slot_len + part_want - 1) / part_want;
     if (parts < 1) parts = 1;
