@@ -294,7 +294,13 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
         };
         int cur = 0;
         int period = sg < ns ? table_period(sg) : 0;
-        if (period) build(per, s_freq[sg], period);
+        // frequency whose table a buffer holds (-1: none): the separator comes back every other
+        // segment and finds its table still there
+        int held[2] = {-1, -1};
+        if (period) {
+            build(per, s_freq[sg], period);
+            held[0] = s_freq[sg];
+        }
         __syncthreads();
         while (sg < ns) {
             const int lo = s_start[sg], hi = s_start[sg + 1];
@@ -302,7 +308,10 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
             const int a = lo > p0 ? lo : p0, b = hi < p1 ? hi : p1;
             const int nx = sg + 1;
             const int period_nx = (nx < ns && hi < p1) ? table_period(nx) : 0;
-            if (period_nx) build(per + (cur ^ 1) * SYN_MAX_STRIDE, s_freq[nx], period_nx);
+            if (period_nx && held[cur ^ 1] != (int)s_freq[nx]) {
+                build(per + (cur ^ 1) * SYN_MAX_STRIDE, s_freq[nx], period_nx);
+                held[cur ^ 1] = s_freq[nx];
+            }
             int va = a + ((4 - ((mis + a) & 3)) & 3);    // first aligned vector of the segment
             va = va > b ? b : va;
             const int vb = va + ((b - va) & ~3);         // end of the last one
