@@ -456,20 +456,19 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     const bool tab_lds = ctx->s.tone_n < 16 * SYN_BLOCK || ctx->synth_table_lds;
     const size_t lds = SYN_OFF_TAB + ((tab_lds ? tab_entries : 0) + 2 * SYN_MAX_STRIDE) * esz;
     WN_REQUIRE(lds <= 150 * 1024, "sample_rate too large for the LDS sine table");
-    // one launch = as many workgroups as stay resident, each looping over (frame, part) items
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > (tab_lds ? 2 : 4)) per_cu = tab_lds ? 2 : 4;
-    if (per_cu < 1) per_cu = 1;
-    if (const int v = ctx->synth_per_cu)
-        if (v >= 1 && v <= 2048 / SYN_BLOCK && (size_t)v * lds <= 160 * 1024) per_cu = v;
-    const long long resident = (long long)ctx->num_cus * per_cu;
-    // Large parts amortise the per-part set-up (segment table, first tone): up to 768 Ki samples
-    // (3 MB) when there is enough work for every resident workgroup four times over, smaller ones
-    // (down to 16 Ki) when there are few frames.  Measured on 122 GB, sines computed in the kernel:
-    // 22.5 ms at 48 Ki, 20.6 at 96 Ki, 20.0 at 192 Ki, 19.8 at 384 Ki, 19.7 at 768 Ki and 1.5 Mi.
-    // WN_SYNTH_PART / WN_SYNTH_PER_CU override the choice for tuning.
+    // Work items are (frame, part) pairs, parts of 192 Ki samples (768 KB) when there is plenty of
+    // work, down to 16 Ki for few frames; a workgroup takes every blocks-th item.  The grid is a
+    // quarter of the items (at least what is resident at once: four workgroups per CU by LDS, two
+    // by registers, the rest queue and start in order as others finish): the dispatcher hands
+    // out the items in address order then, and the chip sweeps through the buffer instead of
+    // writing a thousand far-apart regions at once.  Measured on 122 GB (one box, the faster
+    // placement): 1024 workgroups 19.6 ms at parts of 768 Ki and 20.0 at 192 Ki; a quarter of the
+    // items 18.35 ms at 192 Ki, 18.5 at 384 Ki; half of them 18.4 / 18.7 (768 Ki); one workgroup
+    // per item 21.3 (every workgroup of a round in its set-up at the same time).
+    // WN_SYNTH_PART / WN_SYNTH_PER_CU (workgroups per CU of the grid) override the choice for tuning.
+    const long long resident = (long long)ctx->num_cus * (tab_lds ? 2 : 4);
     long long part_want = (n * slot_len / (resident * 4) + 4095) & ~4095ll;
-    part_want = part_want < 16384 ? 16384 : (part_want > 786432 ? 786432 : part_want);
+    part_want = part_want < 16384 ? 16384 : (part_want > 196608 ? 196608 : part_want);
     if (ctx->synth_part >= 4096) part_want = ctx->synth_part;
     long long parts = (slot_len + part_want - 1) / part_want;
     if (parts < 1) parts = 1;
@@ -477,7 +476,10 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     part_len = (part_len + 3) & ~3ll;
     parts = (slot_len + part_len - 1) / part_len;
     const long long items = n * parts;
-    const long long blocks = items < resident ? items : resident;
+    long long blocks = items / 4 > resident ? items / 4 : resident;
+    if (const int v = ctx->synth_per_cu)
+        if (v >= 1 && v <= 4096) blocks = (long long)ctx->num_cus * v;
+    if (blocks > items) blocks = items;
     hipStream_t st = (hipStream_t)stream;
 #define WN_SYNTH_LAUNCH(T, TAB, TABLE)                                                                          \
     hipLaunchKernelGGL((synth_kernel<T, TAB>), dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,      \
