@@ -28,6 +28,7 @@ struct wn_ctx {
     // tuning / diagnostic switches, read from the environment once, when the context is made
     // (WN_DETECT_PROFILE, WN_SYNTH_PER_CU, WN_SYNTH_PART); 0 = not set
     int detect_profile;
+    float detect_share;    // share of the pilot's energy in one column tile that sends a window the one-tile way
     int synth_per_cu;
     int synth_table_lds;   // 1: keep the quarter-wave table in LDS whatever the scheme (WN_SYNTH_TABLE=lds)
     long long synth_part;

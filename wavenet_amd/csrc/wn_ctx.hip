@@ -310,6 +310,11 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
         return WN_ERR_UNSUPPORTED;
     }
     if (const char *e = getenv("WN_DETECT_PROFILE")) ctx->detect_profile = atoi(e) != 0;
+    ctx->detect_share = 0.7f;
+    if (const char *e = getenv("WN_DETECT_SHARE")) {
+        const float v = (float)atof(e);
+        if (v > 0.34f && v <= 1.0f) ctx->detect_share = v;
+    }
     if (const char *e = getenv("WN_SYNTH_PER_CU")) ctx->synth_per_cu = atoi(e);
     if (const char *e = getenv("WN_SYNTH_TABLE")) ctx->synth_table_lds = e[0] == 'l';
     if (const char *e = getenv("WN_SYNTH_PART")) ctx->synth_part = atoll(e);

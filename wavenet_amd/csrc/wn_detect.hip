@@ -1130,8 +1130,9 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     const double k = (1.0 - ctx->tie_band) * (1.0 - ctx->tie_band) / (1.0 + 1.0 / 2048.0) * (1.0 - 1e-6);
     // A window goes the one-column-tile way when the pilot finds this share of its energy in one
     // tile.  Measured on clean and noisy frames: 0.5 -> 9 % of the windows done twice, 0.6 -> 3 %,
-    // 0.7 -> 0.25 %, 0.8 and 0.9 -> none, but more windows the whole way; 0.7 is the fastest.
-    const float share = 0.7f;
+    // 0.7 -> 0.25 %, 0.8 and 0.9 -> none, but more windows the whole way; 0.7 is the fastest
+    // (again after the later changes: 30.0 / 29.8 / 29.6 / 30.1 / 30.5 ms at 0.6 / 0.65 / 0.7 / 0.75 / 0.8).
+    const float share = ctx->detect_share;   // 0.7 unless WN_DETECT_SHARE said otherwise when the context was made
     if (ctx->detect_profile)
         hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
