@@ -456,19 +456,22 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     const bool tab_lds = ctx->s.tone_n < 16 * SYN_BLOCK || ctx->synth_table_lds;
     const size_t lds = SYN_OFF_TAB + ((tab_lds ? tab_entries : 0) + 2 * SYN_MAX_STRIDE) * esz;
     WN_REQUIRE(lds <= 150 * 1024, "sample_rate too large for the LDS sine table");
-    // Work items are (frame, part) pairs, parts of 192 Ki samples (768 KB) when there is plenty of
-    // work, down to 16 Ki for few frames; a workgroup takes every blocks-th item.  The grid is a
-    // quarter of the items (at least what is resident at once: four workgroups per CU by LDS, two
+    // Work items are (frame, part) pairs, parts of 48 Ki samples (192 KB) when there is plenty of
+    // work, down to 16 Ki for few frames; a workgroup takes every blocks-th item.  The grid is an
+    // eighth of the items (at least what is resident at once: four workgroups per CU by LDS, two
     // by registers, the rest queue and start in order as others finish): the dispatcher hands
     // out the items in address order then, and the chip sweeps through the buffer instead of
-    // writing a thousand far-apart regions at once.  Measured on 122 GB (one box, the faster
-    // placement): 1024 workgroups 19.6 ms at parts of 768 Ki and 20.0 at 192 Ki; a quarter of the
-    // items 18.35 ms at 192 Ki, 18.5 at 384 Ki; half of them 18.4 / 18.7 (768 Ki); one workgroup
-    // per item 21.3 (every workgroup of a round in its set-up at the same time).
+    // writing a thousand far-apart regions at once.  Measured on 122 GB (the faster placement):
+    // 1024 persistent workgroups 19.6 ms at parts of 768 Ki, 20.0 at 192 Ki, 22.5 at 48 Ki; a
+    // quarter of the items 18.35 ms at 192 Ki, 17.7 at 48 Ki; an eighth of them 18.0 at 96 Ki, 17.3
+    // at 48 Ki, 17.3-17.7 at 36 Ki; a sixteenth 17.65 at 48 Ki; smaller parts (24 Ki: 19 ms, 12 Ki:
+    // 29 ms) pay too much set-up; one workgroup per item 21.3 ms (every workgroup of a round in
+    // its set-up at the same time).
     // WN_SYNTH_PART / WN_SYNTH_PER_CU (workgroups per CU of the grid) override the choice for tuning.
     const long long resident = (long long)ctx->num_cus * (tab_lds ? 2 : 4);
     long long part_want = (n * slot_len / (resident * 4) + 4095) & ~4095ll;
-    part_want = part_want < 16384 ? 16384 : (part_want > 196608 ? 196608 : part_want);
+    const long long part_max = tab_lds ? 196608 : 49152;   // a workgroup with the table in LDS loads 44 KB first: fewer, larger parts
+    part_want = part_want < 16384 ? 16384 : (part_want > part_max ? part_max : part_want);
     if (ctx->synth_part >= 4096) part_want = ctx->synth_part;
     long long parts = (slot_len + part_want - 1) / part_want;
     if (parts < 1) parts = 1;
@@ -476,7 +479,8 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     part_len = (part_len + 3) & ~3ll;
     parts = (slot_len + part_len - 1) / part_len;
     const long long items = n * parts;
-    long long blocks = items / 4 > resident ? items / 4 : resident;
+    const long long share = tab_lds ? 4 : 8;
+    long long blocks = items / share > resident ? items / share : resident;
     if (const int v = ctx->synth_per_cu)
         if (v >= 1 && v <= 4096) blocks = (long long)ctx->num_cus * v;
     if (blocks > items) blocks = items;
