@@ -322,7 +322,7 @@ def main():
     if not args.no_pick and 2 * sub * per_stream <= 0.85 * free:
         try:
             other = torch.empty((sub, stride), dtype=torch.float32, device=device)
-        except torch.OutOfMemoryError:
+        except RuntimeError:   # out of memory: keep the one buffer
             other = None
         if other is not None:
             pf, pl = m.build_frames(fields[:sub], pay[:sub], 128)
