@@ -14,7 +14,7 @@ from wavenet_amd import modem as M  # noqa: E402
 
 assert int(os.environ.get("WN_DETECT_PROFILE", "0")), "set WN_DETECT_PROFILE=1"
 m = M.Modem(M.esquema_b())
-S = 2000
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 stride = M.pad4(m.esquema.max_frame_samples(126))
 nwin = stride // 7055
 g = torch.Generator().manual_seed(1)
@@ -39,3 +39,6 @@ for what, audio in (("noise", 0.3 * torch.randn((S, stride), device="cuda")), ("
         print("  %-22s %8.0f clocks/window" % (n, c * 256.0 / nw))
     print("  %-22s %8.0f clocks/window" % ("total", v[7] * 256.0 / nw))
     print("  shader clock %.3f GHz" % (v[7] / v[8] * 0.1))
+    t = mag.view(-1)[16:16 + 1024].double() * 1e-5   # ms
+    print("  waves ran %.3f / %.3f / %.3f ms (min / mean / max): the launch waits %.2f %% for its slowest wave"
+          % (t.min().item(), t.mean().item(), t.max().item(), 100.0 * (t.max().item() / t.mean().item() - 1.0)))

@@ -904,6 +904,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // out_bin[0..6]: clocks/256 per phase (DMA wait, pilot of stage 1 and the column tiles' rough
         // energies, stores + next DMA issue, stage 2 with its arg-max work and checks, decision,
         // energy of the window, rest of stage 1); [7]: total clocks/256; [8]: 100 MHz ticks/256
+        // out_mag[16 + 4*workgroup + wave]: 100 MHz ticks this wave ran (how far apart the waves finish)
+        if (lane == 0) out_mag[16 + 4 * blockIdx.x + wave] = (float)(__builtin_amdgcn_s_memrealtime() - prof_r0);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             for (int i = 0; i < 7; ++i) out_bin[i] = (int)(prof[i] >> 8);
             out_bin[7] = (int)((__builtin_amdgcn_s_memtime() - prof_c0) >> 8);
