@@ -47,15 +47,48 @@ def test_no_alloc_detection_equals_the_allocating_one():
         audio, stride = _capture(n_streams, n_windows, seed)
         want, _, _ = m.detect(audio, n_streams, stride, n_windows, first_sample=1)
         got = torch.full((n_streams, n_windows), -1, dtype=torch.int16, device="cuda")
-        before = torch.cuda.memory_allocated()
+        torch.cuda.synchronize()
+        # free bytes of the device as the driver counts them: an allocation by the library (hipMalloc,
+        # hipMallocAsync, a pool growing) shows here, which torch's own counters would not see
+        free_before = torch.cuda.mem_get_info()[0]
+        torch_before = torch.cuda.memory_reserved()
         rc = L.lib.wn_detect_windows_noalloc(m._ctx, C.c_void_p(audio.data_ptr()), audio.numel(), n_streams, stride, 1,
                                              n_windows, C.c_void_p(got.data_ptr()),
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == L.WN_OK, L.lib.wn_last_error()
         torch.cuda.synchronize()
-        assert torch.cuda.memory_allocated() == before
+        assert torch.cuda.mem_get_info()[0] == free_before and torch.cuda.memory_reserved() == torch_before
         assert torch.equal(got, want)
         assert len(set(want.cpu().numpy().ravel().tolist())) > 3   # the capture was not trivial
+
+
+def test_no_alloc_detection_under_graph_capture():
+    """The use the entry point is for: captured once in a HIP graph (where any allocation, and any
+    synchronising call, fails the capture), replayed on two different captures of audio, each replay
+    equal to wn_detect_windows on the same audio."""
+    m = M.Modem(M.esquema_b())
+    n_streams, n_windows = 5, 9
+    first, stride = _capture(n_streams, n_windows, 11)
+    second, _ = _capture(n_streams, n_windows, 12)
+    audio = first.clone()
+    got = torch.full((n_streams, n_windows), -1, dtype=torch.int16, device="cuda")
+    m.detect_classes_into(audio, n_streams, stride, n_windows, got, first_sample=1)   # code objects loaded before the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rc = L.lib.wn_detect_windows_noalloc(m._ctx, C.c_void_p(audio.data_ptr()), audio.numel(), n_streams, stride, 1,
+                                             n_windows, C.c_void_p(got.data_ptr()),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == L.WN_OK, L.lib.wn_last_error()
+    for src in (second, first):
+        audio.copy_(src)
+        got.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        want, _, _ = m.detect(src, n_streams, stride, n_windows, first_sample=1)
+        assert torch.equal(got, want)
+    assert not torch.equal(m.detect(first, n_streams, stride, n_windows, first_sample=1)[0],
+                           m.detect(second, n_streams, stride, n_windows, first_sample=1)[0])
 
 
 def test_no_alloc_detection_refuses_more_than_its_workspace_holds():

@@ -130,6 +130,17 @@ def main():
                     "frac": by / mean / 1e6 / 8000, "frames_per_s": n / mean * 1e3,
                     "row_traffic_GBps": n * 140 / mean / 1e6, "units": "%d frames, stride 128" % n,
                     "invalid_found": int(failed.sum())})
+        # the lane-parallel kernel (per-distance tables, eight lanes per row, DPP combine) on the same rows
+        os.environ["WN_CRC_COMBINE"] = "1"
+        mc = M.Modem(M.esquema_b())
+        del os.environ["WN_CRC_COMBINE"]
+        assert torch.equal(mc.parse_frames(rows, nbytes), rec), "both checksum kernels give the same records"
+        mean, best = timed(lambda: mc.parse_frames(rows, nbytes), args.reps)
+        out.append({"kernel": "crc_combine_kernel<parse+validate>", "bound": "hbm", "ms": mean, "ms_min": best,
+                    "algorithmic_bytes": by, "achieved_GBps": by / mean / 1e6, "peak_GBps": 8000,
+                    "frac": by / mean / 1e6 / 8000, "frames_per_s": n / mean * 1e3,
+                    "row_traffic_GBps": n * 140 / mean / 1e6, "units": "%d frames, stride 128" % n,
+                    "records_equal_the_row_kernel": True})
         del rows
 
     if "long" in only:

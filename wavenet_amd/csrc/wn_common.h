@@ -25,6 +25,8 @@ struct wn_ctx {
     int32_t ping_lo, ping_hi;
     // checksum: slicing-by-4 tables [4][256]
     uint32_t *d_crc_tab;
+    uint32_t *d_crc_combine_tab;   // per-distance tables of the lane-parallel kernel (wn_crc_frames.hip)
+    int crc_combine;               // WN_CRC_COMBINE=1: that kernel instead of one lane per row (stride 128)
     // tuning / diagnostic switches, read from the environment once, when the context is made
     // (WN_DETECT_PROFILE, WN_SYNTH_PER_CU, WN_SYNTH_PART); 0 = not set
     int detect_profile;
@@ -75,6 +77,8 @@ static inline int wn_launch_check(const char *kernel) {
 
 // host tables (wn_ctx.hip)
 void wn_host_crc_tables(uint32_t tab[4][256]);
+void wn_host_crc_combine_tables(uint32_t *out);   // wn_host_crc_combine_words() entries
+size_t wn_host_crc_combine_words();
 int wn_plan_lookup(int32_t n, int32_t *n1, int32_t *n2);
 
 // Per-device set-up of each kernel file (dynamic-LDS limits of its kernels, addresses of its

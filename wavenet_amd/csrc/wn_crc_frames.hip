@@ -122,6 +122,158 @@ __global__ __launch_bounds__(CRC_BLOCK) void crc_rows_kernel(const uint8_t *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same two operations with a lane-parallel combine instead of one lane walking a row
+// (selected by WN_CRC_COMBINE=1 when the context is made; stride 128 only).
+//
+// A CRC register is linear over GF(2) in the message bits, so the checksum of an L-byte row is
+//     ~( XOR_i  T[L-1-i][ M_i ]  ^  INIT[L] ),
+// where T[e][b] is the register after byte b followed by e zero bytes (start value 0) and INIT[L]
+// the register after L zero bytes from the start value 0xFFFFFFFF.  Every byte's term is one
+// look-up that depends on nothing else: no carried state, no order.  Eight lanes hold the eight
+// 16-byte pieces of a row exactly as one coalesced load delivers them (a wave-wide 16-byte load
+// is eight whole rows), each lane XORs the 16 terms of its own piece, and three DPP steps XOR the
+// eight partial registers together.  The tables for every distance a 128-byte row can have
+// (128 x 1 KiB, plus 15 all-zero ones below them so that bytes past the end of the message need no
+// mask: their distance is negative and lands there) fill 143 KiB of LDS per CU.
+// Nothing is staged, no lane waits for a longer row in its wave, and the look-ups of a lane are
+// independent; the price is 16 look-ups per lane whatever the row's length (2 per row and wave
+// instruction, about what the longest row of 64 costs the one-lane-per-row kernel).
+// ---------------------------------------------------------------------------------------
+#define CMB_ZERO_ROWS 15
+#define CMB_MAX_LEN 128
+#define CMB_TAB_ROWS (CMB_ZERO_ROWS + CMB_MAX_LEN)
+#define CMB_WORDS (CMB_TAB_ROWS * 256 + CMB_MAX_LEN + 4)   // tables, then INIT[0..128]
+#define CMB_BLOCK 1024
+#define CMB_WAVES (CMB_BLOCK / 64)
+#define CMB_UNROLL 4   // groups of eight rows a wave has in flight
+
+// the tables of the combine kernel, as the kernel lays them out (host side; wn_scheme_init uploads them)
+void wn_host_crc_combine_tables(uint32_t *out) {
+    static uint32_t tab[4][256];
+    wn_host_crc_tables(tab);
+    for (int i = 0; i < CMB_ZERO_ROWS * 256; ++i) out[i] = 0u;
+    uint32_t *t = out + CMB_ZERO_ROWS * 256;
+    for (int b = 0; b < 256; ++b) t[b] = tab[0][b];
+    for (int e = 1; e < CMB_MAX_LEN; ++e)
+        for (int b = 0; b < 256; ++b) {
+            const uint32_t v = t[(e - 1) * 256 + b];
+            t[e * 256 + b] = (v >> 8) ^ tab[0][v & 0xFF];
+        }
+    uint32_t *init = out + CMB_TAB_ROWS * 256;
+    uint32_t st = 0xFFFFFFFFu;
+    for (int l = 0; l <= CMB_MAX_LEN; ++l) {
+        init[l] = st;
+        st = (st >> 8) ^ tab[0][st & 0xFF];
+    }
+    for (int l = CMB_MAX_LEN + 1; l < CMB_MAX_LEN + 4; ++l) init[l] = 0u;
+}
+size_t wn_host_crc_combine_words() { return CMB_WORDS; }
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_xor(uint32_t v) {
+    return v ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(CMB_BLOCK) void crc_combine_kernel(const uint8_t *__restrict__ rows,
+                                                                const int32_t *__restrict__ lens, long long n,
+                                                                const uint32_t *__restrict__ g_tabs,
+                                                                uint32_t *__restrict__ out32,
+                                                                wn_frame_rec *__restrict__ out_rec) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *tabs = (uint32_t *)smem;
+    {
+        const uint4 *src = (const uint4 *)g_tabs;
+        uint4 *dst = (uint4 *)smem;
+        for (int i = threadIdx.x; i < CMB_WORDS / 4; i += CMB_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t *init = tabs + CMB_TAB_ROWS * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 7, sub = lane >> 3;   // piece of the row, row of the group
+    constexpr int TILE = 8 * CMB_UNROLL;       // rows a wave takes at a time
+    const long long n_tiles = (n + TILE - 1) / TILE;
+    const long long tstep = (long long)gridDim.x * CMB_WAVES;
+    long long t = (long long)blockIdx.x * CMB_WAVES + wave;
+    uint4 v[CMB_UNROLL], nv[CMB_UNROLL];
+    int ln[CMB_UNROLL], nl[CMB_UNROLL];
+    auto load = [&](long long tile, uint4 (&vv)[CMB_UNROLL], int (&ll)[CMB_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < CMB_UNROLL; ++u) {
+            const long long row = tile * TILE + 8 * u + sub;
+            vv[u] = make_uint4(0u, 0u, 0u, 0u);
+            ll[u] = 0;
+            if (row < n) {
+                // the whole 128-byte line of a row comes from HBM whatever part of it is asked for
+                vv[u] = ((const uint4 *)(rows + row * 128))[c];
+                ll[u] = lens[row];
+            }
+        }
+    };
+    if (t < n_tiles) load(t, v, ln);
+    for (; t < n_tiles; t += tstep) {
+        if (t + tstep < n_tiles) load(t + tstep, nv, nl);
+#pragma unroll
+        for (int u = 0; u < CMB_UNROLL; ++u) {
+            const long long row = t * TILE + 8 * u + sub;
+            int len = ln[u];
+            len = len < 0 ? 0 : (len > CMB_MAX_LEN ? CMB_MAX_LEN : len);
+            int crc_len = len;
+            wn_frame_rec rec;
+            rec.crc = 0; rec.crc_ok = 0; rec.tipo = 0; rec.length = 0; rec.status = WN_ST_OK;
+            int body = 0;
+            if constexpr (MODE == 1) {
+                // type and length bytes sit in piece 0: every lane of the row gets them from its lane
+                const uint32_t w3 = (uint32_t)__shfl((int)v[u].w, lane & ~7);
+                crc_len = 0;
+                if (len == 0) {
+                    rec.status = WN_ST_EMPTY;
+                } else if (len < 15) {
+                    rec.status = WN_ST_SHORT_HEADER;
+                } else {
+                    rec.tipo = (uint8_t)(w3 >> 8);
+                    rec.length = (uint8_t)(w3 >> 16);
+                    body = 15 + rec.length;
+                    if (len < body + 4) rec.status = WN_ST_SHORT_BODY;
+                    else crc_len = body;
+                }
+            }
+            // table of the last byte of this piece is base + 0, of its first byte base + 15; pieces
+            // that start at or after the end of the message contribute nothing
+            const int base = crc_len - 16 * c - 16 + CMB_ZERO_ROWS;   // table row (with the zero rows) of byte 15 of the piece
+            const bool live = 16 * c < crc_len;
+            const uint32_t *tb = tabs + (live ? base : 0) * 256;
+            const uint32_t d[4] = {live ? v[u].x : 0u, live ? v[u].y : 0u, live ? v[u].z : 0u, live ? v[u].w : 0u};
+            uint32_t x = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x ^= tb[(15 - k) * 256 + ((d[k >> 2] >> (8 * (k & 3))) & 0xFF)];
+            x = dpp_xor<0xB1>(x);    // lanes 2j, 2j+1
+            x = dpp_xor<0x4E>(x);    // quads
+            x = dpp_xor<0x141>(x);   // both quads of the row's eight lanes
+            const uint32_t crc = ~(x ^ init[crc_len]);
+            if (c == 0 && row < n) {
+                if constexpr (MODE == 0) {
+                    out32[row] = crc;
+                } else {
+                    if (rec.status == WN_ST_OK) {
+                        const uint8_t *p = rows + row * 128 + body;   // the line is in the cache
+                        const uint32_t stored = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+                        rec.crc = crc;
+                        rec.crc_ok = stored == crc;
+                    }
+                    out_rec[row] = rec;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CMB_UNROLL; ++u) {
+            v[u] = nv[u];
+            ln[u] = nl[u];
+        }
+    }
+}
+
 // Fallback for strides the tiled kernel does not take: one lane per row, bytes from HBM.
 template <int MODE>
 __global__ __launch_bounds__(CRC_BLOCK) void crc_rows_generic_kernel(const uint8_t *__restrict__ rows,
@@ -214,6 +366,10 @@ int wn_crc_device_setup(int) {
                                    4096 + CRC_WAVES * 64 * (512 + 4)));
     WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_rows_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    4096 + CRC_WAVES * 64 * (512 + 4)));
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_combine_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   CMB_WORDS * 4));
+    WN_HIP_TRY(hipFuncSetAttribute((const void *)crc_combine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   CMB_WORDS * 4));
     return WN_OK;
 }
 
@@ -223,6 +379,14 @@ static int launch_rows(wn_ctx *ctx, const uint8_t *rows, const int32_t *lens, in
     if (n == 0) return WN_OK;
     WN_REQUIRE_DEVICE(ctx);
     const bool tiled = (stride % 16 == 0) && stride >= 16 && stride <= 512 && (((uintptr_t)rows) % 16 == 0);
+    if (ctx->crc_combine && stride == 128 && (((uintptr_t)rows) % 16 == 0)) {
+        const long long tiles = (n + 8 * CMB_UNROLL - 1) / (8 * CMB_UNROLL);
+        long long blocks = (tiles + CMB_WAVES - 1) / CMB_WAVES;
+        if (blocks > (long long)ctx->num_cus) blocks = ctx->num_cus;   // the tables fill a CU's LDS: one workgroup each
+        hipLaunchKernelGGL(crc_combine_kernel<MODE>, dim3((unsigned)blocks), dim3(CMB_BLOCK), CMB_WORDS * 4, st, rows, lens,
+                           (long long)n, ctx->d_crc_combine_tab, out32, out_rec);
+        return wn_launch_check("crc_combine_kernel");
+    }
     if (tiled) {
         const size_t lds = 4096 + (size_t)CRC_WAVES * 64 * (stride + 4);
         const long long tiles = (n + 63) / 64;

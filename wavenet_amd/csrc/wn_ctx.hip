@@ -207,6 +207,7 @@ extern "C" int wn_ctx_destroy(wn_ctx *ctx) {
     (void)hipFree(ctx->d_tw2);
     (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_crc_tab);
+    (void)hipFree(ctx->d_crc_combine_tab);
     free(ctx);
     return WN_OK;
 }
@@ -302,6 +303,12 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
         wn_host_crc_tables(tab);
         INIT_TRY(upload(&ctx->d_crc_tab, &tab[0][0], (size_t)4 * 256));
     }
+    {
+        std::vector<uint32_t> t(wn_host_crc_combine_words());
+        wn_host_crc_combine_tables(t.data());
+        INIT_TRY(upload(&ctx->d_crc_combine_tab, t.data(), t.size()));
+    }
+    if (const char *e = getenv("WN_CRC_COMBINE")) ctx->crc_combine = atoi(e) != 0;
     INIT_HIP(hipMalloc((void **)&ctx->d_stats, 8 * sizeof(unsigned long long)));
     INIT_HIP(hipMemset(ctx->d_stats, 0, 8 * sizeof(unsigned long long)));
     if ((size_t)(ctx->n + n1 + n2) * sizeof(double2) > 150 * 1024) {

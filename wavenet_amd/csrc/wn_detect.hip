@@ -67,6 +67,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -1135,7 +1136,9 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     // 0.7 -> 0.25 %, 0.8 and 0.9 -> none, but more windows the whole way; 0.7 is the fastest
     // (again after the later changes: 30.0 / 29.8 / 29.6 / 30.1 / 30.5 ms at 0.6 / 0.65 / 0.7 / 0.75 / 0.8).
     const float share = ctx->detect_share;   // 0.7 unless WN_DETECT_SHARE said otherwise when the context was made
-    if (ctx->detect_profile)
+    // the profiling build leaves its clock counts in out_bin[0..8] and out_mag[16 .. 16 + 4*blocks):
+    // launches whose result arrays are shorter than that run the ordinary build
+    if (ctx->detect_profile && total >= 16 + 4 * blocks)
         hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share,
@@ -1155,6 +1158,7 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
 #define NOALLOC_HEAD 256   // bytes: the four counters of the float64 pass, padded
 static __device__ __align__(256) unsigned char scratch[NOALLOC_HEAD + 8ull * WN_DETECT_NOALLOC_MAX_WINDOWS];
 static unsigned char *g_scratch_ptr[WN_MAX_DEVICES];   // written once per device, under wn_scheme_init's lock
+static std::mutex g_noalloc_mutex[WN_MAX_DEVICES];
 
 template <int N1, int N2>
 static int detect_attr() {
@@ -1256,6 +1260,10 @@ extern "C" int wn_detect_windows_noalloc(wn_ctx *ctx, const float *d_audio, int6
         return WN_ERR_HIP;
     }
     hipStream_t st = (hipStream_t)stream;
+    // The clearing and the three launches of a call are enqueued as one unit: two threads calling at
+    // once cannot interleave them.  (Calls enqueued on different streams may still run at the same
+    // time on the GPU, which the caller must rule out: the lock orders enqueueing, not execution.)
+    std::lock_guard<std::mutex> hold(g_noalloc_mutex[ctx->device]);
     // the counters start at zero in every call; magnitudes and bins are written for every window
     // of the call before they are read, so what the previous call left there does not matter
     WN_HIP_TRY(hipMemsetAsync(ws, 0, NOALLOC_HEAD, st));

@@ -45,6 +45,11 @@ __device__ __forceinline__ unsigned wn_m0_get() {
 }
 __device__ __forceinline__ void wn_m0_set(unsigned v) {
     v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);   // the same in every lane; no cost when already scalar
+    // The compiler does not know that M0 changes here (it refuses M0 in a clobber list as a
+    // reserved register).  Between a wn_m0_set and the one that restores the saved value there must
+    // be no instruction of the compiler's own that uses M0 (indexed register moves, lane reads by
+    // M0, LDS instructions that take their base from it): tools/check_m0.py disassembles the built
+    // kernels and fails if any instruction other than these moves and the DMA loads touches M0.
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(v) : "memory");
 }
 template <int OFF, bool X4>

@@ -316,11 +316,39 @@ def _escuchar_trama_por_tramos(c, m, tw):
         cls, _, _ = m.detect(audio, 1, audio.numel(), nuevas, base + k * n)
         k += nuevas
         todas = torch.cat([todas, cls], dim=1)
-        by, lens, _, end, _, _ = m.slice(torch.cat([todas, vacia], dim=1).contiguous(), tw, 1, 288)
+        by, lens, _, end, reason, _ = m.slice(torch.cat([todas, vacia], dim=1).contiguous(), tw, 1, 288)
         usados = int(end[0, 0])
         if usados <= k or k >= 2 * tw:
-            return by, lens, min(usados, k)
+            return by, lens, min(usados, k), todas, int(reason[0, 0])
         c.confirmar(base + k * n)
+
+
+def _registrar_ventanas(clases, usados, razon):
+    """The lines the reference's receive loop logs window by window (c1_shared.py:310, 320,
+    333, 338, 344-351), replayed from the class words of the windows one listen call consumed."""
+    logging.info("Escuchando... (esperando datos hasta EOF 7000 Hz)")
+    oyo_ping, espera_silencio = False, True
+    for w in np.asarray(clases[:usados]).astype(np.uint16).tolist():
+        if not oyo_ping:
+            if w & L.CLS_PING:
+                oyo_ping = True
+                logging.info("Escuche el ping")
+            continue
+        if w & L.CLS_EOF:
+            logging.info("EOF detectado.")
+            return
+        byte = w & L.CLS_BYTE_MASK
+        if byte != L.CLS_NONE:
+            if espera_silencio:
+                logging.info("?------------?")
+                continue
+            logging.info(f"BYTE <- {byte}")
+            espera_silencio = True
+        else:
+            espera_silencio = False
+            logging.info("--------------")
+    if (razon & 0xFF) == L.END_TIMEOUT:
+        logging.info("Timeout alcanzado. Terminando escucha.")
 
 
 def escuchar_y_retornar_trama(timeout):
@@ -329,13 +357,15 @@ def escuchar_y_retornar_trama(timeout):
     c, m = canal(), modem()
     tw = m.timeout_windows(timeout)
     if c.incremental:
-        by, lens, usados = _escuchar_trama_por_tramos(c, m, tw)
+        by, lens, usados, cls, razon = _escuchar_trama_por_tramos(c, m, tw)
     else:
         audio, desde, nwin = _ventanas_disponibles(c, 2 * tw)
         cls, _, _ = m.detect(audio, 1, audio.numel(), nwin, desde)
-        by, lens, _, end, _, _ = m.slice(cls, tw, 1, 288)
-        usados = int(end[0, 0])
+        by, lens, _, end, reason, _ = m.slice(cls, tw, 1, 288)
+        usados, razon = int(end[0, 0]), int(reason[0, 0])
     c.leido += usados * c.esquema.win_n
+    if logging.getLogger().isEnabledFor(logging.INFO):    # the class words leave the GPU only when somebody reads the log
+        _registrar_ventanas(cls[0].cpu().numpy(), usados, razon)
     recibidos = by[0, 0, :int(lens[0, 0])].cpu().numpy().tolist()
     logging.info(f"{recibidos}")
     return Trama(bytes_trama=recibidos)
