@@ -778,6 +778,40 @@ def test_slice_long_frames_across_chunk_boundaries(mb):
                 assert bytes(by[s, j, :lens[s, j]]) == b[:128], (s, tw, j)
 
 
+def test_slice_long_captures(mb):
+    """Captures of more than 2048 windows take the sixteen-wave form of the kernel (tables for
+    98 304 windows in LDS, calls in batches of 128), longer ones the single-wave machine over class
+    words staged 16 384 at a time: random class words with frames, timeouts and symbol runs that
+    straddle the multiples of 4096 and 16 384, a capture that ends exactly on one, calls that run
+    out in the middle, more calls than a batch holds, and the call limit reached before the
+    capture ends."""
+    rng = np.random.default_rng(23)
+    NONE, PING, EOF = 256, 256 | 512, 256 | 1024
+    pool = np.array([NONE] * 12 + [PING, EOF] + [7, 7, 9, 200, 255, 0, 33, 33], dtype=np.uint16)
+    for n_windows in (2049, 16384, 16385, 40000, 98304, 100000):
+        n_streams = 12 if n_windows < 90000 else 3
+        cls = pool[rng.integers(0, len(pool), (n_streams, n_windows))]
+        # a frame of alternating separator / byte windows across each stage boundary, phase by stream
+        for s in range(n_streams):
+            for edge in (16384, 32768):
+                if edge + 200 < n_windows:
+                    lo = edge - 90 - s
+                    cls[s, lo] = PING
+                    body = np.where(np.arange(1, 170) % 2 == (s & 1), NONE, 40 + (np.arange(1, 170) // 2) % 200)
+                    cls[s, lo + 1:lo + 170] = body.astype(np.uint16)
+                    cls[s, lo + 170] = EOF
+        for tw, max_calls in ((700, 64), (50, 3000), (20000, 5), (64, 7)):
+            by, lens, start, end, reason, ncalls = [t.cpu().numpy() for t in
+                                                    mb.slice(dev(cls.astype(np.int16)), tw, max_calls, 96)]
+            for s in range(n_streams):
+                want = mo.slice_classes(cls[s], tw, max_calls)
+                assert ncalls[s] == len(want), (n_windows, s, tw)
+                for j, (w0, w1, b, r) in enumerate(want):
+                    assert (start[s, j], end[s, j], reason[s, j] & 0xFF) == (w0, w1, r), (n_windows, s, tw, j)
+                    assert bytes(by[s, j, :lens[s, j]]) == b[:96], (n_windows, s, tw, j)
+                    assert bool(reason[s, j] & L.END_OVERFLOW) == (len(b) > 96)
+
+
 def test_contexts_of_both_schemes_on_one_device(golden):
     """Making the short-window context after the long-window one must leave the long one fully
     usable, its float64 pass (whose phase table is the largest dynamic LDS request) included."""
