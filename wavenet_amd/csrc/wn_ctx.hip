@@ -349,13 +349,13 @@ extern "C" int wn_detect_set_tie_band(wn_ctx *ctx, double rel) {
     return WN_OK;
 }
 
-extern "C" int wn_detect_stats(wn_ctx *ctx, int64_t out[6], void *stream) {
+extern "C" int wn_detect_stats(wn_ctx *ctx, int64_t out[8], void *stream) {
     WN_REQUIRE(ctx && out, "ctx/out");
     unsigned long long h[8];
     hipStream_t st = (hipStream_t)stream;
     WN_HIP_TRY(hipMemcpyAsync(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost, st));
     WN_HIP_TRY(hipMemsetAsync(ctx->d_stats, 0, sizeof(h), st));
     WN_HIP_TRY(hipStreamSynchronize(st));
-    for (int i = 0; i < 6; ++i) out[i] = (int64_t)h[i];
+    for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
     return WN_OK;
 }

@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
 
     unsigned long long s1_units = 0;    // (row tile, real or imaginary part, column) products of stage 1 this wave computed (statistics)
     unsigned long long redone = 0;      // windows done a second time, the whole way
+    unsigned long long whole_n = 0;     // windows that took the whole-spectrum way (those done twice included)
     int next_off = 0;
     if (w < total) {
         next_off = fetch(f_s, f_w);
@@ -804,6 +805,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             // among the rest each time it has to go on
             stage1(ic<WHOLE>{}, ic<0>{});
             s1_units += OTHER_TILES * P::K2;
+            ++whole_n;
             after_stage1(ic<0>{});
             have_max = false;
             unsigned todo = (1u << C2T) - 1u;
@@ -900,6 +902,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         atomicAdd(&stats[3], cells_done);
         atomicAdd(&stats[4], s1_units);
         if (redone) atomicAdd(&stats[5], redone);
+        if (whole_n) atomicAdd(&stats[6], whole_n);
     }
     if constexpr (PROF) {
         // out_bin[0..6]: clocks/256 per phase (DMA wait, pilot of stage 1 and the column tiles' rough
@@ -995,16 +998,24 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                 const bool three = (f & FLAG_TOP3) != 0;
                 const int b1 = f & 0xFFFF, b2 = cls[wi], b3 = three ? __float_as_int(mag[wi]) : b1;
                 double r1 = 0, i1 = 0, r2 = 0, i2 = 0, r3 = 0, i3 = 0;
+                // phases (b*n) mod N of this thread's samples n = tid, tid + 256, ...: advanced by
+                // (256*b) mod N per step instead of reduced anew
+                const unsigned uN = (unsigned)N;
+                unsigned m1 = (unsigned)(b1 * tid) % uN, m2 = (unsigned)(b2 * tid) % uN, m3 = (unsigned)(b3 * tid) % uN;
+                const unsigned d1 = (unsigned)(b1 * 256) % uN, d2 = (unsigned)(b2 * 256) % uN, d3 = (unsigned)(b3 * 256) % uN;
                 for (int n = tid; n < N; n += 256) {
                     const double xv = (double)x[n];
-                    const double2 t1 = phase((unsigned)(b1 * n) % (unsigned)N);
-                    const double2 t2 = phase((unsigned)(b2 * n) % (unsigned)N);
+                    const double2 t1 = phase(m1);
+                    const double2 t2 = phase(m2);
                     r1 += xv * t1.x; i1 += xv * t1.y;
                     r2 += xv * t2.x; i2 += xv * t2.y;
                     if (three) {
-                        const double2 t3 = phase((unsigned)(b3 * n) % (unsigned)N);
+                        const double2 t3 = phase(m3);
                         r3 += xv * t3.x; i3 += xv * t3.y;
+                        m3 += d3; m3 = m3 >= uN ? m3 - uN : m3;
                     }
+                    m1 += d1; m1 = m1 >= uN ? m1 - uN : m1;
+                    m2 += d2; m2 = m2 >= uN ? m2 - uN : m2;
                 }
                 r1 = wave_sum(r1); i1 = wave_sum(i1); r2 = wave_sum(r2); i2 = wave_sum(i2);
                 r3 = wave_sum(r3); i3 = wave_sum(i3);

@@ -184,17 +184,26 @@ __global__ __launch_bounds__(THREADS) void slice_scan_kernel(const uint16_t *__r
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint16_t *c = cls + s * n_windows;
     const int n = (int)n_windows, nch = (n + 63) >> 6;
-    // ---- phase 1: masks per chunk
-    for (int k = wave; k < nch; k += WAVES) {
-        const int x = 64 * k + lane;
-        const int cw = x < n ? c[x] : WN_CLS_NONE;
-        const unsigned long long p = __ballot((cw & WN_CLS_PING) != 0);
-        const unsigned long long e = __ballot((cw & WN_CLS_EOF) != 0);
-        const unsigned long long b = __ballot((cw & WN_CLS_BYTE_MASK) != WN_CLS_NONE);
-        if (lane == 0) {
-            pm[k] = p;
-            em[k] = e;
-            sym[k] = b;
+    // ---- phase 1: masks per chunk; the class words of eight chunks are requested before the first
+    // ballot waits for them
+    for (int k0 = wave; k0 < nch; k0 += 8 * WAVES) {
+        int cw[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int x = 64 * (k0 + q * WAVES) + lane;
+            cw[q] = x < n ? c[x] : WN_CLS_NONE;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q * WAVES;
+            const unsigned long long p = __ballot((cw[q] & WN_CLS_PING) != 0);
+            const unsigned long long e = __ballot((cw[q] & WN_CLS_EOF) != 0);
+            const unsigned long long b = __ballot((cw[q] & WN_CLS_BYTE_MASK) != WN_CLS_NONE);
+            if (lane == 0 && k < nch) {
+                pm[k] = p;
+                em[k] = e;
+                sym[k] = b;
+            }
         }
     }
     __syncthreads();

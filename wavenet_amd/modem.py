@@ -211,13 +211,14 @@ class Modem:
     def set_tie_band(self, rel: float):
         L.check(L.lib.wn_detect_set_tie_band(self._ctx, float(rel)), "wn_detect_set_tie_band")
 
-    def detect_stats(self, columns: bool = False):
+    def detect_stats(self, columns: bool = False, paths: bool = False):
         """[windows, two-bin float64 re-evaluations, whole-spectrum ones] since the last call; with
         `columns` also the spectrum columns whose second stage was computed, the (row tile,
-        column) products of the first stage that were, and the windows that were done twice."""
-        out = (C.c_int64 * 6)()
+        column) products of the first stage that were, and the windows that were done twice; with
+        `paths` also the windows whose first stage covered every column tile."""
+        out = (C.c_int64 * 8)()
         L.check(L.lib.wn_detect_stats(self._ctx, out, _stream()), "wn_detect_stats")
-        return list(out) if columns else list(out)[:3]
+        return list(out)[:7 if paths else (6 if columns else 3)]
 
     def sync_scan(self, audio: torch.Tensor, n_streams: int, stream_stride: int, n_windows: int, first_sample: int = 0):
         """Ping correlator (the test of escuchar_ping, c1_shared.py:380-382) per window:
@@ -245,12 +246,11 @@ class Modem:
         n_streams, n_windows = cls.shape
         assert cls.dtype == torch.int16 and cls.is_contiguous()
         by = torch.zeros((n_streams, max_calls, frame_cap), dtype=torch.uint8, device=self.device)
-        shape = (n_streams, max_calls)
-        lens = torch.zeros(shape, dtype=torch.int32, device=self.device)
-        start = torch.zeros(shape, dtype=torch.int32, device=self.device)
-        end = torch.zeros(shape, dtype=torch.int32, device=self.device)
-        reason = torch.zeros(shape, dtype=torch.int32, device=self.device)
-        n_calls = torch.zeros(n_streams, dtype=torch.int32, device=self.device)
+        # the five integer results in one zeroed allocation (one fill instead of five)
+        k = n_streams * max_calls
+        meta = torch.zeros(4 * k + n_streams, dtype=torch.int32, device=self.device)
+        lens, start, end, reason = (meta[i * k:(i + 1) * k].view(n_streams, max_calls) for i in range(4))
+        n_calls = meta[4 * k:]
         L.check(L.lib.wn_slice_frames(self._ctx, _ptr(cls), n_streams, n_windows, timeout_windows, max_calls,
                                       frame_cap, _ptr(by), _ptr(lens), _ptr(start), _ptr(end), _ptr(reason),
                                       _ptr(n_calls), _stream()), "wn_slice_frames")
