@@ -38,6 +38,9 @@ for what, audio in (("noise", 0.3 * torch.randn((S, stride), device="cuda")), ("
     for n, c in zip(names, v):
         print("  %-22s %8.0f clocks/window" % (n, c * 256.0 / nw))
     print("  %-22s %8.0f clocks/window" % ("total", v[7] * 256.0 / nw))
+    extra = kbin.view(-1)[9:12].tolist()
+    print("  of the pilot: sample reads %.0f, folds %.0f, matrix instructions %.0f clocks/window"
+          % tuple(c * 256.0 / nw for c in extra))
     print("  shader clock %.3f GHz" % (v[7] / v[8] * 0.1))
     t = mag.view(-1)[16:16 + 1024].double() * 1e-5   # ms
     print("  waves ran %.3f / %.3f / %.3f ms (min / mean / max): the launch waits %.2f %% for its slowest wave"

@@ -118,9 +118,13 @@ struct Plan {
     static_assert(16 * TA <= N1 && KS2 <= 4 * TA && C2T >= 2 && C2T <= 4 && N / 2 <= (int)KEY_BIN &&
                       256 * (NDW - 1) < 4096 && 4 * N1 * (KS1 - 1) < 65536,
                   "plan limits");
-    // LDS map (bytes): class table, then one window buffer per wave
+    // pilot: bf16 matrix instructions of K = 32, k-steps 8m .. 8m+7 of lane group g in slots 8g .. 8g+7
+    static constexpr int NM = (KS1 + 7) / 8;
+    // LDS map (bytes): class table, the pilot's B operands (16 bytes per lane for each of
+    // NM x C2T x {cos, -sin}), then one window buffer per wave
     static constexpr int OFF_LUT = 0;
-    static constexpr int OFF_XW = OFF_LUT + (((N / 2) * 2 + 15) & ~15);
+    static constexpr int OFF_PTW = OFF_LUT + (((N / 2) * 2 + 15) & ~15);
+    static constexpr int OFF_XW = OFF_PTW + NM * C2T * 2 * 1024;
     static constexpr size_t LDS = (size_t)OFF_XW + (size_t)4 * XW * 4;
     // idempotents of the index map: bin of Z[j][k2] is (j*E1 + k2*E2) mod N
     static constexpr int idem(int own, int other) {
@@ -180,6 +184,21 @@ __device__ __forceinline__ void mfma2a_acc(floatx4 &acc, float a_acc, float b_ac
 }
 __device__ __forceinline__ void mfma2a_new(floatx4 &acc, float a_acc, float b_acc) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc) : "a"(a_acc), "a"(b_acc));
+}
+// The pilot's matrix instruction: bf16 operands (8 per lane: A[row lane&15][k = 8(lane>>4) + j],
+// B[k = 8(lane>>4) + j][column lane&15]), f32 sums laid out like those of the f32 instruction.
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_bf16_new(floatx4 &acc, uintx4 a, uintx4 b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_bf16_acc(floatx4 &acc, uintx4 a, uintx4 b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// (bf16(lo), bf16(hi)) in one register
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 // a value that lives in an accumulation register from here on
@@ -252,6 +271,27 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < N / 2; i += 256) lut_s[i] = lut[i];
+    // the pilot's B operands: entry (m, c, part) of lane l holds, for j < 8, the bf16 twiddle of
+    // folded sample column b' = (8m + j) + KS1*(l>>4) and spectrum column k2 = 16c + (l&15)
+    // (cos, halved for b' = 0, or -sin; zero for padding)
+    for (int e = threadIdx.x; e < P::NM * C2T * 2 * 64; e += 256) {
+        const int idx = e >> 6, ln = e & 63, part = idx & 1, c = (idx >> 1) % C2T, m = idx / (2 * C2T);
+        const int k2 = 16 * c + (ln & 15);
+        unsigned h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ks = 8 * m + j, bp = ks + KS1 * (ln >> 4);
+            float v = 0.f;
+            if (ks < KS1 && bp <= H2 && k2 <= H2) {
+                const float2 t = g_tw2[(bp * k2) % N2];
+                v = part ? t.y : (bp == 0 ? 0.5f * t.x : t.x);
+            }
+            const unsigned u = __float_as_uint(v);
+            h[j] = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;   // round to nearest even (finite values)
+        }
+        uintx4 w4 = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        *(uintx4 *)(smem + P::OFF_PTW + idx * 1024 + ln * 16) = w4;
+    }
 
     const int li = lane & 15;  // A row / B column / D column
     const int lg = lane >> 4;  // A,B k index / D row group
@@ -445,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     };
 
     // PROF build only: shader clocks spent per phase of the window loop, summed over this wave's windows
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = 0;
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = 0;
     const unsigned long long prof_r0 = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const unsigned long long prof_c0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](auto I) {
@@ -489,27 +529,22 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         floatx2 raw_p[2][TA], raw_m[2][TA], xs[TA], xd[TA];   // samples: two sets, for even and odd k-steps
         floatx2 e4[TA];            // running sums of the squared A operands, per row-tile pair
         floatx2 sx[TA];            // running sums of the A operands (.x: the sum of the four samples)
-        float keep_s[KS1], keep_d[KS1];   // A operands of the difference tile of pair 0, k-step by k-step
-        // Stage 1 comes in three cuts.  PILOT: the sum row tile 0 (rows a' < 16) of every column
-        // tile, from which the energy of each column tile is estimated (real parts alone make
-        // the estimate too poor: four times as many windows had to be done twice).  WHOLE: every
-        // other row tile of every column tile.  ONE<c>: every other row tile of column tile c
-        // only, for windows whose energy the pilot finds in one column tile.
+        floatx2 xs0[KS1], xd0[KS1];   // A operands of row-tile pair 0 for every k-step, folded by the pilot
+        // Stage 1 comes in two cuts.  WHOLE: every row tile of every column tile.  ONE<c>: every row
+        // tile of column tile c only, for windows whose energy the pilot (below) finds in one
+        // column tile.
         // The sample reads of k-step ks+2 are issued one after each matrix instruction of k-step
         // ks (an LDS instruction issues while the matrix pipe works on the one before it; the
         // vector instructions of the folds do not), into the register set that the fold of
         // k-step ks has already consumed.
         // (Doing the k-steps in pairs, for half as many changes between matrix and vector work, was
         // slower: 24 LDS reads in one go exceed the 15 the wave may have outstanding.)
-        constexpr int PILOT = 0, WHOLE = 1, ONE = 2;
+        constexpr int WHOLE = 1, ONE = 2;
         auto stage1 = [&](auto CUT_, auto CSEL_) {
             constexpr int CUT = decltype(CUT_)::value, CSEL = decltype(CSEL_)::value;
-            // row-tile pairs gathered: the pilot takes pair 0 (and keeps the operands of its
-            // difference tile for the other cuts), the other cuts take the rest
-            constexpr int P0 = CUT == PILOT ? 0 : 1, NP = CUT == PILOT ? 1 : TA - 1;
-            auto rd1 = [&](auto KS, auto M) {   // issue sample read M (of 4*NP) of k-step KS
-                constexpr int ks = decltype(KS)::value, m = decltype(M)::value, pr = P0 + m / 4, q = m % 4;
-                if constexpr (ks < KS1 && m < 4 * NP) {
+            auto rd1 = [&](auto KS, auto M) {   // issue sample read M (of 4*(TA-1)) of k-step KS: row-tile pairs 1 .. TA-1
+                constexpr int ks = decltype(KS)::value, m = decltype(M)::value, pr = 1 + m / 4, q = m % 4;
+                if constexpr (ks < KS1 && m < 4 * (TA - 1)) {
                     if constexpr (q == 0) raw_p[ks & 1][pr][0] = *(const float *)(smem + ad_p[pr] + 4 * N1 * ks);
                     if constexpr (q == 1) raw_m[ks & 1][pr][0] = *(const float *)(smem + ad_m[pr] + 4 * N1 * (KS1 - 1 - ks));
                     if constexpr (q == 2) raw_p[ks & 1][pr][1] = *(const float *)(smem + ad_p[pr + TA] + 4 * N1 * ks);
@@ -517,35 +552,29 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 }
             };
             auto rd = [&](auto KS) {   // all sample reads of k-step KS
-                static_for<4 * NP>([&](auto M) { rd1(KS, M); });
+                static_for<4 * (TA - 1)>([&](auto M) { rd1(KS, M); });
             };
             auto fold = [&](auto KS) {   // samples of k-step KS -> its A operands: fold columns, then rows
                 constexpr int ks = decltype(KS)::value;
-                static_for<NP>([&](auto T) {
-                    constexpr int t = P0 + decltype(T)::value;
+                static_for<TA - 1>([&](auto T) {
+                    constexpr int t = 1 + decltype(T)::value;
                     const floatx2 sab = raw_p[ks & 1][t] + raw_m[ks & 1][t], dab = raw_p[ks & 1][t] - raw_m[ks & 1][t];   // (sa, sb), (da, db)
                     xs[t] = pk_butterfly(sab);                                            // (sa + sb, sa - sb)
                     xd[t] = pk_butterfly(dab);
-                    if constexpr (CUT == PILOT) {
-                        keep_s[ks] = xs[t].y;
-                        keep_d[ks] = xd[t].y;
+                    if constexpr (ks == 0) {
+                        e4[t] = (xs[t] * xs[t] + xd[t] * xd[t]) * w_first;
+                        sx[t] = xs[t] * w_first;
+                    } else if constexpr (ks == KS1 - 1) {
+                        e4[t] += (xs[t] * xs[t] + xd[t] * xd[t]) * w_last;
+                        sx[t] += xs[t] * w_last;
+                    } else {
+                        e4[t] += xs[t] * xs[t];
+                        e4[t] += xd[t] * xd[t];
+                        sx[t] += xs[t];
                     }
-                    {
-                        if constexpr (ks == 0) {
-                            e4[t] = (xs[t] * xs[t] + xd[t] * xd[t]) * w_first;
-                            sx[t] = xs[t] * w_first;
-                        } else if constexpr (ks == KS1 - 1) {
-                            e4[t] += (xs[t] * xs[t] + xd[t] * xd[t]) * w_last;
-                            sx[t] += xs[t] * w_last;
-                        } else {
-                            e4[t] += xs[t] * xs[t];
-                            e4[t] += xd[t] * xd[t];
-                            sx[t] += xs[t];
-                        }
-                        // keeps the sums here, between the matrix instructions of two k-steps (left to
-                        // itself the compiler holds every k-step's operands and squares them after stage 1)
-                        asm volatile("" : "+v"(e4[t]), "+v"(sx[t]));
-                    }
+                    // keeps the sums here, between the matrix instructions of two k-steps (left to
+                    // itself the compiler holds every k-step's operands and squares them after stage 1)
+                    asm volatile("" : "+v"(e4[t]), "+v"(sx[t]));
                 });
             };
             rd(ic<0>{});
@@ -559,13 +588,13 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 static_for<C2T>([&](auto C) {
                     static_for<T1>([&](auto T) {
                         constexpr int c = decltype(C)::value, t = decltype(T)::value;
-                        constexpr bool mine = CUT == PILOT ? t == 0 : (t != 0 && (CUT == WHOLE || c == CSEL));
+                        constexpr bool mine = CUT == WHOLE || c == CSEL;
                         // position of this pair of matrix instructions in the k-step
-                        constexpr int idx = CUT == PILOT ? c : (CUT == ONE ? t - 1 : c * (T1 - 1) + t - 1);
+                        constexpr int idx = CUT == ONE ? t : c * T1 + t;
                         if constexpr (mine) {
-                            // the difference tile of pair 0 takes the operands the pilot kept
-                            const float as = t == TA ? keep_s[ks] : xs[t % TA][t / TA];
-                            const float ad = t == TA ? keep_d[ks] : xd[t % TA][t / TA];
+                            // row-tile pair 0 takes the operands the pilot folded and kept
+                            const float as = t % TA == 0 ? xs0[ks][t / TA] : xs[t % TA][t / TA];
+                            const float ad = t % TA == 0 ? xd0[ks][t / TA] : xd[t % TA][t / TA];
                             if constexpr (ks == 0) mfma1_new(Yr[c][t], as, t2c[ks][c]);
                             else mfma1_acc(Yr[c][t], as, t2c[ks][c]);
                             rd1(ic<ks + 2>{}, ic<2 * idx>{});
@@ -610,18 +639,100 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             sqrt_e = __builtin_amdgcn_sqrtf(e_half);
         };
 
-        stage1(ic<PILOT>{}, ic<0>{});
-        s1_units += 2 * P::K2;
+        // The pilot says where the energy is before any full-precision work is done: the sum row
+        // tile 0 (rows a' < 16 and their mirror images) of every column tile in bf16, whose matrix
+        // instructions are sixteen times as fast as the f32 ones.  Its result only chooses which
+        // column tile stage 1 computes and in which order stage 2 goes: the energy check makes
+        // the window's result independent of it, and everything that reaches a decision or a
+        // magnitude is computed in f32 below.  (With this row tile in f32 and its results kept for
+        // stage 2 the pilot took 3.4 k of a window's 15.9 k clocks.)
+        floatx4 pr[C2T], pi[C2T];
+        {
+            unsigned pa_s[4 * P::NM], pa_d[4 * P::NM];   // A operands: (sum, difference) of the mirrored columns, 8 k-steps per 4 registers
+            // every sample read is issued before the first one is waited for (nothing else runs
+            // meanwhile that could hide one read's latency behind the next one's)
+            floatx2 rp[KS1], rm[KS1];   // rows a' and n1-a': column b', column n2-b'
+            static_for<KS1>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value;
+                rp[ks][0] = *(const float *)(smem + ad_p[0] + 4 * N1 * ks);
+                rm[ks][0] = *(const float *)(smem + ad_m[0] + 4 * N1 * (KS1 - 1 - ks));
+                rp[ks][1] = *(const float *)(smem + ad_p[TA] + 4 * N1 * ks);
+                rm[ks][1] = *(const float *)(smem + ad_m[TA] + 4 * N1 * (KS1 - 1 - ks));
+            });
+            uintx4 bc[P::NM][C2T], bs[P::NM][C2T];   // the twiddles, read while the folds run
+            static_for<P::NM>([&](auto MM) {
+                static_for<C2T>([&](auto C) {
+                    constexpr int m = decltype(MM)::value, c = decltype(C)::value;
+                    bc[m][c] = *(const uintx4 *)(smem + P::OFF_PTW + ((m * C2T + c) * 2) * 1024 + lane * 16);
+                    bs[m][c] = *(const uintx4 *)(smem + P::OFF_PTW + ((m * C2T + c) * 2 + 1) * 1024 + lane * 16);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lap(ic<8>{});
+            float hs = 0.f, hd = 0.f;
+            static_for<8 * P::NM>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value;
+                float sv = 0.f, dv = 0.f;
+                if constexpr (ks < KS1) {
+                    // the fold of stage 1 for this row-tile pair, kept for its matrix instructions below
+                    const floatx2 sab = rp[ks] + rm[ks], dab = rp[ks] - rm[ks];
+                    xs0[ks] = pk_butterfly(sab);
+                    xd0[ks] = pk_butterfly(dab);
+                    if constexpr (ks == 0) {
+                        e4[0] = (xs0[ks] * xs0[ks] + xd0[ks] * xd0[ks]) * w_first;
+                        sx[0] = xs0[ks] * w_first;
+                    } else if constexpr (ks == KS1 - 1) {
+                        e4[0] += (xs0[ks] * xs0[ks] + xd0[ks] * xd0[ks]) * w_last;
+                        sx[0] += xs0[ks] * w_last;
+                    } else {
+                        e4[0] += xs0[ks] * xs0[ks];
+                        e4[0] += xd0[ks] * xd0[ks];
+                        sx[0] += xs0[ks];
+                    }
+                    sv = xs0[ks].x;
+                    dv = xd0[ks].x;
+                }
+                if constexpr (ks % 2 == 0) {
+                    hs = sv;
+                    hd = dv;
+                } else if constexpr (ks - 1 < KS1) {
+                    pa_s[ks / 2] = pk_bf16(hs, sv);
+                    pa_d[ks / 2] = pk_bf16(hd, dv);
+                } else {
+                    pa_s[ks / 2] = 0u;
+                    pa_d[ks / 2] = 0u;
+                }
+            });
+            if constexpr (PROF) asm volatile("" :: "v"(pa_s[0]), "v"(pa_d[0]), "v"(pa_s[4 * P::NM - 1]), "v"(pa_d[4 * P::NM - 1]));
+            lap(ic<9>{});
+            static_for<P::NM>([&](auto MM) {
+                constexpr int m = decltype(MM)::value;
+                const uintx4 as = {pa_s[4 * m], pa_s[4 * m + 1], pa_s[4 * m + 2], pa_s[4 * m + 3]};
+                const uintx4 ad = {pa_d[4 * m], pa_d[4 * m + 1], pa_d[4 * m + 2], pa_d[4 * m + 3]};
+                static_for<C2T>([&](auto C) {
+                    constexpr int c = decltype(C)::value;
+                    if constexpr (m == 0) {
+                        mfma_bf16_new(pr[c], as, bc[m][c]);
+                        mfma_bf16_new(pi[c], ad, bs[m][c]);
+                    } else {
+                        mfma_bf16_acc(pr[c], as, bc[m][c]);
+                        mfma_bf16_acc(pi[c], ad, bs[m][c]);
+                    }
+                });
+            });
+        }
         mfma_drain();
+        lap(ic<10>{});
         // rough energy of each column tile (rows a' < 16 of it, mirrored pairs summed): where the
         // second stage starts, and whether one column tile holds nearly everything
         float ec[C2T];
         unsigned eo[C2T];
 #pragma unroll
         for (int c = 0; c < C2T; ++c) {
-            after_drain_a(Yr[c][0]);
-            after_drain_a(Yi[c][0]);
-            const floatx4 yr = Yr[c][0], yi = Yi[c][0];
+            after_drain(pr[c]);
+            after_drain(pi[c]);
+            const floatx4 yr = pr[c], yi = pi[c];
             ec[c] = (yr.x * yr.x + yi.x * yi.x) + (yr.y * yr.y + yi.y * yi.y) + (yr.z * yr.z + yi.z * yi.z) +
                     (yr.w * yr.w + yi.w * yi.w);
             eo[c] = lane63(__float_as_uint(wave_sum63(ec[c])));   // non-negative floats order like their bits
@@ -746,7 +857,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             });
             return done;
         };
-        constexpr int OTHER_TILES = 2 * T1 - 2;   // (row tile, real or imaginary part) pairs of stage 1 beside the pilot's
+        constexpr int OTHER_TILES = 2 * T1;   // (row tile, real or imaginary part) pairs of stage 1
 
         // ------------------------------------------------------------------ the rest of stage 1, stage 2
         auto after_stage1 = [&](auto SPLIT) {
@@ -912,6 +1023,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         if (lane == 0) out_mag[16 + 4 * blockIdx.x + wave] = (float)(__builtin_amdgcn_s_memrealtime() - prof_r0);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             for (int i = 0; i < 7; ++i) out_bin[i] = (int)(prof[i] >> 8);
+            for (int i = 8; i < 12; ++i) out_bin[i + 1] = (int)(prof[i] >> 8);   // parts of the pilot: reads, folds, matrix instructions
             out_bin[7] = (int)((__builtin_amdgcn_s_memtime() - prof_c0) >> 8);
             out_bin[8] = (int)((__builtin_amdgcn_s_memrealtime() - prof_r0) >> 8);
         }
