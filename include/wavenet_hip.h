@@ -89,6 +89,9 @@ typedef struct wn_frame_rec {
 /* Sample formats for wn_synth_batch. */
 #define WN_FMT_F32 0             /* clip(amp*sin*gain) as float (B:391-393)                */
 #define WN_FMT_I16 1             /* int16(amp*sin*32767), truncated (B:467; A:173)         */
+#define WN_SYNTH_BESIDE 0x100    /* or-ed in: the small-footprint kernel (256 threads, < 48 registers, < 10 KB LDS),
+                                    whose workgroups fit on CUs that a wn_detect_windows launch on another stream
+                                    occupies; the same samples (no counterpart in the reference)                */
 
 const char *wn_strerror(int code);
 /* Text of the last failure on the calling thread (HIP error string or argument name). */

@@ -218,6 +218,36 @@ def test_synth_sines_computed_on_the_gpu_equal_the_host_table(monkeypatch):
     assert np.array_equal(got["computed"][1], mo.wav_int16(frames[0], sch))
 
 
+@pytest.mark.parametrize("plan", ["live", "long_periods"])
+def test_synth_small_footprint_kernel_writes_the_same_samples(plan, monkeypatch):
+    """The small-footprint synthesis kernel (256 threads, sines read from the quarter-wave table,
+    period tables of at most 893 samples) against the ordinary one: identical float32 and int16
+    samples, for the live tone plan, for one whose byte tones have no period table (sample by
+    sample from the table), with small parts and slots at every alignment, and nothing written
+    outside the slots."""
+    import dataclasses
+    monkeypatch.setenv("WN_SYNTH_PART", "4096")
+    esq = M.esquema_b() if plan == "live" else dataclasses.replace(M.esquema_b(), base_freq=351, freq_step=71)
+    m = M.Modem(esq)
+    rng = np.random.default_rng(3)
+    msgs = [mo.build_frame(1, MAC_O, MAC_D, 3, bytes(rng.integers(0, 256, k).tolist())) for k in (0, 3, 1, 2)]
+    buf, lens = rows_from(msgs, 32)
+    lay = m.layout(dev(buf), dev(lens))
+    ns = lay[3].cpu().tolist()
+    slot = M.pad4(max(ns) + 40)
+    offs = torch.tensor([k * (slot + 8) + k for k in range(4)], dtype=torch.int64, device="cuda")
+    fill = torch.tensor([ns[0], ns[1] + 13, slot, slot - 2], dtype=torch.int64, device="cuda")
+    for dtype in (torch.float32, torch.int16):
+        lay_d = lay if dtype == torch.float32 else m.layout(dev(buf), dev(lens), L.EMIT_WAV)
+        out = []
+        for beside in (False, True):
+            audio = torch.full((4 * (slot + 8) + 16,), 7, dtype=dtype, device="cuda")
+            m.synth(lay_d, offs, audio, slot, fill if dtype == torch.float32 else None, beside=beside)
+            out.append(audio.cpu().numpy())
+        assert np.array_equal(out[0], out[1]), (plan, dtype)
+        assert (out[0] != 7).any()
+
+
 def test_synth_sample_counts_with_repeats(mb, golden):
     frames = [bytes.fromhex(c["frame"]) for c in golden["sample_counts_b"]]
     buf, lens = rows_from(frames, 128)

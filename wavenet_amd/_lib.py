@@ -36,6 +36,7 @@ ST_OK, ST_EMPTY, ST_SHORT_HEADER, ST_SHORT_BODY = 0, 1, 2, 3
 END_EOF, END_TIMEOUT, END_OVERFLOW = 0, 1, 0x100
 EMIT_LIVE, EMIT_WAV = 0, 1
 FMT_F32, FMT_I16 = 0, 1
+SYNTH_BESIDE = 0x100   # or-ed into the format: the small-footprint synthesis kernel
 DETECT_NOALLOC_MAX_WINDOWS = 1 << 20
 
 _vp, _i32, _i64, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64

@@ -74,6 +74,12 @@
 #include "wn_common.h"
 #include "wn_dma.h"
 
+// 1: the pilot keeps the folded operands of row-tile pair 0 for stage 1 (44 more registers, 509 of
+// a SIMD lane's 512 in all: about 1.5 % faster alone); 0: stage 1 gathers and folds that pair again
+// (448 registers, which leaves room on every SIMD for a wave of a small kernel on another stream).
+#ifndef WN_DETECT_KEEP0
+#define WN_DETECT_KEEP0 1
+#endif
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
@@ -542,9 +548,11 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         constexpr int WHOLE = 1, ONE = 2;
         auto stage1 = [&](auto CUT_, auto CSEL_) {
             constexpr int CUT = decltype(CUT_)::value, CSEL = decltype(CSEL_)::value;
-            auto rd1 = [&](auto KS, auto M) {   // issue sample read M (of 4*(TA-1)) of k-step KS: row-tile pairs 1 .. TA-1
-                constexpr int ks = decltype(KS)::value, m = decltype(M)::value, pr = 1 + m / 4, q = m % 4;
-                if constexpr (ks < KS1 && m < 4 * (TA - 1)) {
+            // row-tile pairs gathered here: all of them, or all but pair 0 when the pilot kept its operands
+            constexpr int P0 = WN_DETECT_KEEP0 ? 1 : 0, NP = TA - P0;
+            auto rd1 = [&](auto KS, auto M) {   // issue sample read M (of 4*NP) of k-step KS
+                constexpr int ks = decltype(KS)::value, m = decltype(M)::value, pr = P0 + m / 4, q = m % 4;
+                if constexpr (ks < KS1 && m < 4 * NP) {
                     if constexpr (q == 0) raw_p[ks & 1][pr][0] = *(const float *)(smem + ad_p[pr] + 4 * N1 * ks);
                     if constexpr (q == 1) raw_m[ks & 1][pr][0] = *(const float *)(smem + ad_m[pr] + 4 * N1 * (KS1 - 1 - ks));
                     if constexpr (q == 2) raw_p[ks & 1][pr][1] = *(const float *)(smem + ad_p[pr + TA] + 4 * N1 * ks);
@@ -552,12 +560,12 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 }
             };
             auto rd = [&](auto KS) {   // all sample reads of k-step KS
-                static_for<4 * (TA - 1)>([&](auto M) { rd1(KS, M); });
+                static_for<4 * NP>([&](auto M) { rd1(KS, M); });
             };
             auto fold = [&](auto KS) {   // samples of k-step KS -> its A operands: fold columns, then rows
                 constexpr int ks = decltype(KS)::value;
-                static_for<TA - 1>([&](auto T) {
-                    constexpr int t = 1 + decltype(T)::value;
+                static_for<NP>([&](auto T) {
+                    constexpr int t = P0 + decltype(T)::value;
                     const floatx2 sab = raw_p[ks & 1][t] + raw_m[ks & 1][t], dab = raw_p[ks & 1][t] - raw_m[ks & 1][t];   // (sa, sb), (da, db)
                     xs[t] = pk_butterfly(sab);                                            // (sa + sb, sa - sb)
                     xd[t] = pk_butterfly(dab);
@@ -593,8 +601,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                         constexpr int idx = CUT == ONE ? t : c * T1 + t;
                         if constexpr (mine) {
                             // row-tile pair 0 takes the operands the pilot folded and kept
-                            const float as = t % TA == 0 ? xs0[ks][t / TA] : xs[t % TA][t / TA];
-                            const float ad = t % TA == 0 ? xd0[ks][t / TA] : xd[t % TA][t / TA];
+                            const float as = (WN_DETECT_KEEP0 && t % TA == 0) ? xs0[ks][t / TA] : xs[t % TA][t / TA];
+                            const float ad = (WN_DETECT_KEEP0 && t % TA == 0) ? xd0[ks][t / TA] : xd[t % TA][t / TA];
                             if constexpr (ks == 0) mfma1_new(Yr[c][t], as, t2c[ks][c]);
                             else mfma1_acc(Yr[c][t], as, t2c[ks][c]);
                             rd1(ic<ks + 2>{}, ic<2 * idx>{});
@@ -659,14 +667,15 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 rp[ks][1] = *(const float *)(smem + ad_p[TA] + 4 * N1 * ks);
                 rm[ks][1] = *(const float *)(smem + ad_m[TA] + 4 * N1 * (KS1 - 1 - ks));
             });
-            uintx4 bc[P::NM][C2T], bs[P::NM][C2T];   // the twiddles, read while the folds run
-            static_for<P::NM>([&](auto MM) {
+            uintx4 bc[P::NM][C2T], bs[P::NM][C2T];   // the twiddles: those of the first k-steps are read while the folds run
+            auto twiddles = [&](auto MM) {
                 static_for<C2T>([&](auto C) {
                     constexpr int m = decltype(MM)::value, c = decltype(C)::value;
                     bc[m][c] = *(const uintx4 *)(smem + P::OFF_PTW + ((m * C2T + c) * 2) * 1024 + lane * 16);
                     bs[m][c] = *(const uintx4 *)(smem + P::OFF_PTW + ((m * C2T + c) * 2 + 1) * 1024 + lane * 16);
                 });
-            });
+            };
+            if constexpr (WN_DETECT_KEEP0) twiddles(ic<0>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             lap(ic<8>{});
@@ -674,7 +683,11 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             static_for<8 * P::NM>([&](auto KS) {
                 constexpr int ks = decltype(KS)::value;
                 float sv = 0.f, dv = 0.f;
-                if constexpr (ks < KS1) {
+                if constexpr (ks < KS1 && !WN_DETECT_KEEP0) {
+                    const floatx2 sab = rp[ks] + rm[ks], dab = rp[ks] - rm[ks];
+                    sv = sab.x + sab.y;
+                    dv = dab.x + dab.y;
+                } else if constexpr (ks < KS1) {
                     // the fold of stage 1 for this row-tile pair, kept for its matrix instructions below
                     const floatx2 sab = rp[ks] + rm[ks], dab = rp[ks] - rm[ks];
                     xs0[ks] = pk_butterfly(sab);
@@ -710,6 +723,11 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 constexpr int m = decltype(MM)::value;
                 const uintx4 as = {pa_s[4 * m], pa_s[4 * m + 1], pa_s[4 * m + 2], pa_s[4 * m + 3]};
                 const uintx4 ad = {pa_d[4 * m], pa_d[4 * m + 1], pa_d[4 * m + 2], pa_d[4 * m + 3]};
+                if constexpr (!WN_DETECT_KEEP0) twiddles(ic<m>{});
+                else if constexpr (m + 1 < P::NM) twiddles(ic<m + 1>{});   // arrive while this group of matrix instructions runs
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 1" ::: "memory");      // operands just written, read by the next MFMA
+                __builtin_amdgcn_sched_barrier(0);
                 static_for<C2T>([&](auto C) {
                     constexpr int c = decltype(C)::value;
                     if constexpr (m == 0) {

@@ -132,9 +132,17 @@ __device__ __forceinline__ double sin_quarter(int m, int quarter, double w) {
 }
 
 #define SYN_MAX_STRIDE 2304  // longest tone period kept as a table: 2301 samples + 3 wrapped entries
-#define SYN_OFF_FREQ (((SYN_MAX_SEGS + 1) * 4 + 15) & ~15)
-#define SYN_OFF_PERIOD (SYN_OFF_FREQ + SYN_MAX_SEGS * 2)
-#define SYN_OFF_TAB (SYN_OFF_PERIOD + SYN_MAX_SEGS * 2)
+// LDS map for a segment table of `segs` entries: starts (segs + 1 int32), frequencies, periods, then the tables
+constexpr int syn_off_freq(int segs) { return ((segs + 1) * 4 + 15) & ~15; }
+constexpr int syn_off_period(int segs) { return syn_off_freq(segs) + segs * 2; }
+constexpr int syn_off_tab(int segs) { return syn_off_period(segs) + segs * 2; }
+// The small-footprint instance: 256 threads, a segment table of 320 entries (frames of up to 158
+// bytes), period tables of up to 893 samples (every tone of the live scheme), sines from the
+// quarter-wave table in global memory: under 48 registers and 10 KB of LDS, so that its workgroups
+// find room on a CU whose SIMDs each hold one wave of the detection kernel.
+#define SYN_LEAN_BLOCK 256
+#define SYN_LEAN_SEGS 320
+#define SYN_LEAN_STRIDE 896
 
 // One workgroup owns a contiguous part of one frame's samples and goes through the segments
 // that overlap it.  LDS holds the frame's segment table and two buffers of one tone period
@@ -149,21 +157,23 @@ __device__ __forceinline__ double sin_quarter(int m, int quarter, double w) {
 // aligned vector of a segment are written one by one.  Segments shorter than four periods (and
 // tones whose period does not fit a buffer) take their samples straight from the quarter-wave
 // table.
-template <typename T, bool TAB_LDS>
-__global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
+// BLOCK threads, a segment table of MAXSEGS entries, period tables of MAXSTRIDE entries; SINE_GLOBAL:
+// single sines are read from the quarter-wave table in global memory instead of being computed.
+template <typename T, bool TAB_LDS, int BLOCK, int MAXSEGS, int MAXSTRIDE, bool SINE_GLOBAL>
+__device__ __forceinline__ void synth_body(
     const int32_t *__restrict__ seg_start, const uint16_t *__restrict__ seg_freq, const int32_t *__restrict__ n_segs,
     int seg_cap, long long n_frames, int parts, int part_len, const long long *__restrict__ dst_off,
     const long long *__restrict__ fill_to, T *__restrict__ audio, long long audio_len,
     const T *__restrict__ g_tab, int quarter, int tab_entries, double amp, double gain, double w_unit) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int32_t *s_start = (int32_t *)smem;                        // SYN_MAX_SEGS + 1
-    uint16_t *s_freq = (uint16_t *)(smem + SYN_OFF_FREQ);      // frequency mod sr
-    uint16_t *s_period = (uint16_t *)(smem + SYN_OFF_PERIOD);  // period of the tone, 0 = no table
-    T *tab_s = (T *)(smem + SYN_OFF_TAB);                      // tab_entries (quarter + 1 rounded up to 32)
-    T *per = tab_s + (TAB_LDS ? tab_entries : 0);              // [2][SYN_MAX_STRIDE]
+    int32_t *s_start = (int32_t *)smem;                        // MAXSEGS + 1
+    uint16_t *s_freq = (uint16_t *)(smem + syn_off_freq(MAXSEGS));      // frequency mod sr
+    uint16_t *s_period = (uint16_t *)(smem + syn_off_period(MAXSEGS));  // period of the tone, 0 = no table
+    T *tab_s = (T *)(smem + syn_off_tab(MAXSEGS));                      // tab_entries (quarter + 1 rounded up to 32)
+    T *per = tab_s + (TAB_LDS ? tab_entries : 0);              // [2][MAXSTRIDE]
     const int tid = threadIdx.x;
     if constexpr (TAB_LDS)
-        for (int i = tid; i <= quarter; i += SYN_BLOCK) tab_s[tab_pos(i)] = g_tab[i];
+        for (int i = tid; i <= quarter; i += BLOCK) tab_s[tab_pos(i)] = g_tab[i];
     const int sr = 4 * quarter, half = 2 * quarter;
     const float inv_sr = 1.0f / (float)sr;
     typedef typename Vec4<T>::type V4;
@@ -174,6 +184,8 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
         T v;
         if constexpr (TAB_LDS) {
             v = tab_s[tab_pos(mq)];
+        } else if constexpr (SINE_GLOBAL) {
+            v = g_tab[mq];
         } else {
             const double sn = sin_quarter(mq, quarter, w_unit);
             if constexpr (sizeof(T) == 4) {
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
         return neg ? (T)(-v) : v;
     };
     auto build = [&](T *dst, int f, int period) {   // one period of the f-Hz tone and its first three samples again
-        for (int i = tid; i < period + 3; i += SYN_BLOCK) {
+        for (int i = tid; i < period + 3; i += BLOCK) {
             const int ii = i >= period ? i - period : i;
             dst[i] = sine(mod_sr((unsigned)f * (unsigned)ii, sr, inv_sr));
         }
@@ -202,8 +214,8 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
         const int part = (int)(item - f * parts);
         __syncthreads();  // quarter-wave table ready / previous item's tables no longer read
         const int ns = n_segs[f];
-        for (int i = tid; i <= ns; i += SYN_BLOCK) s_start[i] = seg_start[f * (long long)(seg_cap + 1) + i];
-        for (int i = tid; i < ns; i += SYN_BLOCK) {
+        for (int i = tid; i <= ns; i += BLOCK) s_start[i] = seg_start[f * (long long)(seg_cap + 1) + i];
+        for (int i = tid; i < ns; i += BLOCK) {
             const unsigned fq = (unsigned)seg_freq[f * (long long)seg_cap + i] % (unsigned)sr;
             unsigned g = (unsigned)sr, r = fq;     // gcd(sr, fq) by Euclid; fq = 0 gives sr, a period of one sample
             while (r) {
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
             }
             const unsigned period = (unsigned)sr / g;
             s_freq[i] = (uint16_t)fq;
-            s_period[i] = period + 3 <= SYN_MAX_STRIDE ? (uint16_t)period : (uint16_t)0;
+            s_period[i] = period + 3 <= MAXSTRIDE ? (uint16_t)period : (uint16_t)0;
         }
         __syncthreads();
         const int total = s_start[ns];
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
             }
             sg = lo;
         }
-        if ((long long)total < (long long)ns * (16 * SYN_BLOCK)) {
+        if (!SINE_GLOBAL && (long long)total < (long long)ns * (16 * BLOCK)) {
             // Short segments (fewer than four steps of the workgroup each, as in the prototype
             // scheme): going segment by segment would leave most lanes idle, so the threads
             // walk the part as one run of vectors, each keeping its own current segment.
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
             int hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
             int fq = sg < ns ? s_freq[sg] : 0;
             const int head = (4 - ((mis + p0) & 3)) & 3;        // samples before the first aligned vector
-            for (int p = p0 - ((4 - head) & 3) + 4 * tid; p < p1; p += 4 * SYN_BLOCK) {
+            for (int p = p0 - ((4 - head) & 3) + 4 * tid; p < p1; p += 4 * BLOCK) {
                 const int q0 = p < p0 ? p0 : p;                 // the first vector may start before the part
                 const int q1 = p + 4 < p1 ? p + 4 : p1;
                 while (q0 >= hi) {
@@ -309,19 +321,19 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
             const int nx = sg + 1;
             const int period_nx = (nx < ns && hi < p1) ? table_period(nx) : 0;
             if (period_nx && held[cur ^ 1] != (int)s_freq[nx]) {
-                build(per + (cur ^ 1) * SYN_MAX_STRIDE, s_freq[nx], period_nx);
+                build(per + (cur ^ 1) * MAXSTRIDE, s_freq[nx], period_nx);
                 held[cur ^ 1] = s_freq[nx];
             }
             int va = a + ((4 - ((mis + a) & 3)) & 3);    // first aligned vector of the segment
             va = va > b ? b : va;
             const int vb = va + ((b - va) & ~3);         // end of the last one
             if (period) {
-                const T *tone = per + cur * SYN_MAX_STRIDE;
+                const T *tone = per + cur * MAXSTRIDE;
                 int v = va + 4 * tid;
                 if (v < vb) {
                     int j = (int)((unsigned)(v - lo) % (unsigned)period);
-                    const int jstep = (4 * SYN_BLOCK) % period;
-                    for (; v < vb; v += 4 * SYN_BLOCK) {
+                    const int jstep = (4 * BLOCK) % period;
+                    for (; v < vb; v += 4 * BLOCK) {
                         V4 o;
                         o.x = tone[j]; o.y = tone[j + 1]; o.z = tone[j + 2]; o.w = tone[j + 3];
                         *(V4 *)(out + v) = o;
@@ -334,9 +346,14 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
                     const int lim = tid < 4 ? va : b;
                     if (pos < lim) out[pos] = tone[(unsigned)(pos - lo) % (unsigned)period];
                 }
+            } else if constexpr (SINE_GLOBAL) {
+                // no table for this tone (its period is too long, or the segment too short): sample by
+                // sample from the quarter-wave table; correct, and not meant to be fast
+                const int fq = s_freq[sg];
+                for (int q = a + tid; q < b; q += BLOCK) out[q] = sine(mod_sr((unsigned)fq * (unsigned)(q - lo), sr, inv_sr));
             } else {
                 const int fq = s_freq[sg];
-                for (int v = va + 4 * tid; v < vb; v += 4 * SYN_BLOCK) {
+                for (int v = va + 4 * tid; v < vb; v += 4 * BLOCK) {
                     int m = mod_sr((unsigned)fq * (unsigned)(v - lo), sr, inv_sr);
                     T e[4];
 #pragma unroll
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
             va = va > p1 ? p1 : va;
             const int vb = va + ((p1 - va) & ~3);
             V4 z = {};
-            for (int v = va + 4 * tid; v < vb; v += 4 * SYN_BLOCK) *(V4 *)(out + v) = z;
+            for (int v = va + 4 * tid; v < vb; v += 4 * BLOCK) *(V4 *)(out + v) = z;
             if (tid < 8) {
                 const int pos = tid < 4 ? a + tid : vb + (tid - 4);
                 const int lim = tid < 4 ? va : p1;
@@ -375,6 +392,25 @@ __global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(
             }
         }
     }
+}
+
+#define SYN_ARGS_DECL                                                                                                 \
+    const int32_t *__restrict__ seg_start, const uint16_t *__restrict__ seg_freq, const int32_t *__restrict__ n_segs,   \
+        int seg_cap, long long n_frames, int parts, int part_len, const long long *__restrict__ dst_off,               \
+        const long long *__restrict__ fill_to, T *__restrict__ audio, long long audio_len, const T *__restrict__ g_tab, \
+        int quarter, int tab_entries, double amp, double gain, double w_unit
+#define SYN_ARGS_PASS                                                                                             \
+    seg_start, seg_freq, n_segs, seg_cap, n_frames, parts, part_len, dst_off, fill_to, audio, audio_len, g_tab, quarter, \
+        tab_entries, amp, gain, w_unit
+template <typename T, bool TAB_LDS>
+__global__ __launch_bounds__(SYN_BLOCK) void synth_kernel(SYN_ARGS_DECL) {
+    synth_body<T, TAB_LDS, SYN_BLOCK, SYN_MAX_SEGS, SYN_MAX_STRIDE, false>(SYN_ARGS_PASS);
+}
+// the small-footprint instance, held to 40 registers: a SIMD whose one detection wave holds 464
+// of its 512 registers has 48 left
+template <typename T>
+__global__ __launch_bounds__(SYN_LEAN_BLOCK) __attribute__((amdgpu_num_vgpr(40))) void synth_lean_kernel(SYN_ARGS_DECL) {
+    synth_body<T, false, SYN_LEAN_BLOCK, SYN_LEAN_SEGS, SYN_LEAN_STRIDE, true>(SYN_ARGS_PASS);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -437,6 +473,8 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
                               const int64_t *d_fill_to, int64_t slot_len, void *d_audio, int64_t audio_len,
                               int32_t fmt, void *stream) {
     WN_REQUIRE(ctx && n >= 0, "ctx / n >= 0");
+    const bool beside = (fmt & WN_SYNTH_BESIDE) != 0;
+    fmt &= ~WN_SYNTH_BESIDE;
     WN_REQUIRE(fmt == WN_FMT_F32 || fmt == WN_FMT_I16, "fmt");
     WN_REQUIRE(seg_cap > 0 && seg_cap <= SYN_MAX_SEGS, "0 < seg_cap <= 768");
     WN_REQUIRE(slot_len > 0 && slot_len < (1ll << 31) && audio_len > 0, "0 < slot_len < 2^31 / audio_len > 0");
@@ -454,7 +492,7 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     // Schemes with short tones take every sample from the quarter-wave table and keep it in LDS
     // (WN_SYNTH_TABLE=lds forces that for any scheme: the two must give the same samples).
     const bool tab_lds = ctx->s.tone_n < 16 * SYN_BLOCK || ctx->synth_table_lds;
-    const size_t lds = SYN_OFF_TAB + ((tab_lds ? tab_entries : 0) + 2 * SYN_MAX_STRIDE) * esz;
+    const size_t lds = syn_off_tab(SYN_MAX_SEGS) + ((tab_lds ? tab_entries : 0) + 2 * SYN_MAX_STRIDE) * esz;
     WN_REQUIRE(lds <= 150 * 1024, "sample_rate too large for the LDS sine table");
     // Work items are (frame, part) pairs, parts of 48 Ki samples (192 KB) when there is plenty of
     // work, down to 16 Ki for few frames; a workgroup takes every blocks-th item.  The grid is an
@@ -485,6 +523,23 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
         if (v >= 1 && v <= 4096) blocks = (long long)ctx->num_cus * v;
     if (blocks > items) blocks = items;
     hipStream_t st = (hipStream_t)stream;
+    if (beside && !tab_lds && seg_cap <= SYN_LEAN_SEGS) {
+        // The small-footprint instance (same samples): parts of 48 Ki samples, a grid of an eighth of
+        // the items and at least one workgroup per CU, as above.
+        long long lb = items / 8 > ctx->num_cus ? items / 8 : ctx->num_cus;
+        if (lb > items) lb = items;
+        const size_t llds = syn_off_tab(SYN_LEAN_SEGS) + 2 * SYN_LEAN_STRIDE * esz;
+#define WN_SYNTH_LEAN(T, TABLE)                                                                                    \
+    hipLaunchKernelGGL((synth_lean_kernel<T>),                                                                   \
+                       dim3((unsigned)lb), dim3(SYN_LEAN_BLOCK), llds, st, d_seg_start, d_seg_freq, d_n_segs,      \
+                       (int)seg_cap, (long long)n, (int)parts, (int)part_len, (const long long *)d_dst_off,        \
+                       (const long long *)d_fill_to, (T *)d_audio, (long long)audio_len, (const T *)(TABLE),       \
+                       ctx->quarter, (int)tab_entries, ctx->s.amp, ctx->s.gain, 2.0 * M_PI / (double)ctx->s.sample_rate)
+        if (fmt == WN_FMT_F32) WN_SYNTH_LEAN(float, ctx->d_sin_f32);
+        else WN_SYNTH_LEAN(int16_t, ctx->d_sin_i16);
+#undef WN_SYNTH_LEAN
+        return wn_launch_check("synth_kernel (small footprint)");
+    }
 #define WN_SYNTH_LAUNCH(T, TAB, TABLE)                                                                          \
     hipLaunchKernelGGL((synth_kernel<T, TAB>), dim3((unsigned)blocks), dim3(SYN_BLOCK), lds, st, d_seg_start,      \
                        d_seg_freq, d_n_segs, (int)seg_cap, (long long)n, (int)parts, (int)part_len,                \

@@ -153,18 +153,21 @@ class Modem:
         return seg_start, seg_freq, n_segs, n_samples
 
     def synth(self, layout, dst_off: torch.Tensor, audio: torch.Tensor, slot_len: int,
-              fill_to: torch.Tensor | None = None):
+              fill_to: torch.Tensor | None = None, beside: bool = False):
         """transmite_freq / transmitir_silencio for every segment (c1_shared.py:386-406) into
-        `audio` (float32 or int16, 1-D or [streams, stride] contiguous)."""
+        `audio` (float32 or int16, 1-D or [streams, stride] contiguous).  `beside`: the
+        small-footprint kernel, which finds room on CUs that a detection launch on another
+        stream occupies (the same samples)."""
         seg_start, seg_freq, n_segs, _ = layout
-        fmt = {torch.float32: L.FMT_F32, torch.int16: L.FMT_I16}[audio.dtype]
+        fmt = {torch.float32: L.FMT_F32, torch.int16: L.FMT_I16}[audio.dtype] | (L.SYNTH_BESIDE if beside else 0)
         assert audio.is_contiguous() and dst_off.dtype == torch.int64
         L.check(L.lib.wn_synth_batch(self._ctx, _ptr(seg_start), _ptr(seg_freq), _ptr(n_segs), seg_freq.shape[1],
                                      n_segs.numel(), _ptr(dst_off), _ptr(fill_to), slot_len, _ptr(audio),
                                      audio.numel(), fmt, _stream()), "wn_synth_batch")
 
     def encode_streams(self, frames: torch.Tensor, lens: torch.Tensor, stream_stride: int | None = None,
-                       variant: int = L.EMIT_LIVE, dtype=torch.float32, audio: torch.Tensor | None = None):
+                       variant: int = L.EMIT_LIVE, dtype=torch.float32, audio: torch.Tensor | None = None,
+                       beside: bool = False):
         """emitir_trama (c1_shared.py:415-434) for one frame per stream: returns audio
         [n, stream_stride], each stream zero-filled after its frame."""
         n = frames.shape[0]
@@ -175,7 +178,7 @@ class Modem:
         lay = self.layout(frames, lens, variant)
         dst = torch.arange(n, dtype=torch.int64, device=self.device) * stream_stride
         fill = torch.full((n,), stream_stride, dtype=torch.int64, device=self.device)
-        self.synth(lay, dst, audio, stream_stride, fill)
+        self.synth(lay, dst, audio, stream_stride, fill, beside=beside)
         return audio, lay[3]
 
     def awgn(self, audio: torch.Tensor, sigma: float, seed: int):
