@@ -20,7 +20,7 @@
  *    each enqueueing on its own stream.  Exceptions, all stated at their declarations:
  *    wn_detect_set_tie_band changes the context (a set-up call: not while another thread
  *    detects with it), the counters read by wn_detect_stats are summed over all callers of the
- *    context, and wn_detect_windows_noalloc calls on one GPU must not overlap.
+ *    context, and graph replays of wn_detect_windows_noalloc must not overlap other calls of it.
  */
 #ifndef WAVENET_HIP_H
 #define WAVENET_HIP_H
@@ -192,8 +192,11 @@ int wn_detect_windows(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int6
  * inside the library (one array per GPU, 8 MiB + 256 bytes, held until the process ends), so
  * the call makes no allocation of any kind.  At most WN_DETECT_NOALLOC_MAX_WINDOWS windows
  * (n_streams * n_windows) per call; more is refused with WN_ERR_ARG.  d_cls equals what
- * wn_detect_windows writes.  Calls on one GPU share the workspace: they must not overlap in time
- * (not on two streams, not from two threads); the counters are not reported. */
+ * wn_detect_windows writes.  Calls on one GPU share the workspace.  Outside graph capture the library
+ * orders them itself: a call's work waits, on the GPU, for the previous call's, whichever stream or
+ * thread enqueued it (an event recorded behind every call, no allocation).  A call captured into a
+ * graph takes no part in that ordering: replays of such a graph must not run at the same time as
+ * other calls of this function on the same GPU.  The counters are not reported. */
 #define WN_DETECT_NOALLOC_MAX_WINDOWS (1 << 20)
 int wn_detect_windows_noalloc(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int64_t n_streams,
                               int64_t stream_stride, int64_t first_sample, int64_t n_windows,

@@ -91,6 +91,25 @@ def test_no_alloc_detection_under_graph_capture():
                            m.detect(second, n_streams, stride, n_windows, first_sample=1)[0])
 
 
+def test_no_alloc_calls_on_two_streams_follow_each_other():
+    """Calls enqueued on different streams with nothing between them share the one workspace: the
+    library makes each wait for the one before it, so both results equal wn_detect_windows."""
+    m = M.Modem(M.esquema_b())
+    shapes = ((40, 30, 21), (9, 11, 22), (33, 25, 23), (2, 3, 24))
+    caps = [_capture(s, w, seed) for s, w, seed in shapes]
+    wants = [m.detect(a, s, stride, w, first_sample=1)[0] for (s, w, _), (a, stride) in zip(shapes, caps)]
+    gots = [torch.full((s, w), -1, dtype=torch.int16, device="cuda") for s, w, _ in shapes]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for i, ((s, w, _), (a, stride)) in enumerate(zip(shapes, caps)):
+        rc = L.lib.wn_detect_windows_noalloc(m._ctx, C.c_void_p(a.data_ptr()), a.numel(), s, stride, 1, w,
+                                             C.c_void_p(gots[i].data_ptr()), C.c_void_p(streams[i % 2].cuda_stream))
+        assert rc == L.WN_OK, L.lib.wn_last_error()
+    torch.cuda.synchronize()
+    for got, want in zip(gots, wants):
+        assert torch.equal(got, want)
+
+
 def test_no_alloc_detection_refuses_more_than_its_workspace_holds():
     m = M.Modem(M.esquema_b())
     cls = torch.zeros(4, dtype=torch.int16, device="cuda")

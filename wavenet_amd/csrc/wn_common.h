@@ -88,3 +88,5 @@ int wn_detect_device_setup(int device);
 int wn_sync_device_setup(int device);
 int wn_synth_device_setup(int device);
 int wn_crc_device_setup(int device);
+// whether the sines the synthesis kernel computes equal the host-built table for this context's scheme
+int wn_synth_sines_agree(wn_ctx *ctx, bool *agree);

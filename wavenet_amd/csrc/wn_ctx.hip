@@ -339,6 +339,13 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
             ready[ctx->device] = true;
         }
     }
+    if (!ctx->synth_table_lds) {
+        // the synthesis of long-tone schemes computes its sines on the GPU: only if every one of them
+        // equals the host's table entry (pinned by tests for the shipped schemes, checked here for any)
+        bool agree = false;
+        INIT_TRY(wn_synth_sines_agree(ctx, &agree));
+        if (!agree) ctx->synth_table_lds = 1;
+    }
     *out = ctx;
     return WN_OK;
 }

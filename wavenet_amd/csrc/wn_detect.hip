@@ -1300,6 +1300,11 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
 static __device__ __align__(256) unsigned char scratch[NOALLOC_HEAD + 8ull * WN_DETECT_NOALLOC_MAX_WINDOWS];
 static unsigned char *g_scratch_ptr[WN_MAX_DEVICES];   // written once per device, under wn_scheme_init's lock
 static std::mutex g_noalloc_mutex[WN_MAX_DEVICES];
+// recorded behind the last launch of every call that is not being captured into a graph: the next such
+// call makes its stream wait for it, so that calls enqueued on different streams do not run at the
+// same time on the one workspace
+static hipEvent_t g_noalloc_event[WN_MAX_DEVICES];
+static bool g_noalloc_recorded[WN_MAX_DEVICES];
 
 template <int N1, int N2>
 static int detect_attr() {
@@ -1326,6 +1331,8 @@ int wn_detect_device_setup(int device) {
         return WN_ERR_HIP;
     }
     g_scratch_ptr[device] = (unsigned char *)p;
+    WN_HIP_TRY(hipEventCreateWithFlags(&g_noalloc_event[device], hipEventDisableTiming));
+    g_noalloc_recorded[device] = false;
     return WN_OK;
 }
 
@@ -1402,16 +1409,30 @@ extern "C" int wn_detect_windows_noalloc(wn_ctx *ctx, const float *d_audio, int6
     }
     hipStream_t st = (hipStream_t)stream;
     // The clearing and the three launches of a call are enqueued as one unit: two threads calling at
-    // once cannot interleave them.  (Calls enqueued on different streams may still run at the same
-    // time on the GPU, which the caller must rule out: the lock orders enqueueing, not execution.)
+    // once cannot interleave them.  Outside graph capture the call also waits (on the GPU) for the
+    // previous call's last launch, whatever stream that was on, and leaves an event behind its own:
+    // calls on different streams then follow each other on the workspace instead of racing.  A call
+    // that is being captured into a graph records and waits for nothing (an event from outside the
+    // capture may not be waited for inside it): the replays of such a graph must not overlap with other
+    // calls on the same GPU, which the caller has to see to.
     std::lock_guard<std::mutex> hold(g_noalloc_mutex[ctx->device]);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    WN_HIP_TRY(hipStreamIsCapturing(st, &cap));
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing && g_noalloc_recorded[ctx->device])
+        WN_HIP_TRY(hipStreamWaitEvent(st, g_noalloc_event[ctx->device], 0));
     // the counters start at zero in every call; magnitudes and bins are written for every window
     // of the call before they are read, so what the previous call left there does not matter
     WN_HIP_TRY(hipMemsetAsync(ws, 0, NOALLOC_HEAD, st));
     int32_t *bins = (int32_t *)(ws + NOALLOC_HEAD);
     float *mags = (float *)(ws + NOALLOC_HEAD + 4ull * WN_DETECT_NOALLOC_MAX_WINDOWS);
-    return detect_run(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls, mags, bins,
-                      (unsigned long long *)ws, st);
+    const int rc = detect_run(ctx, d_audio, audio_len, n_streams, stream_stride, first_sample, n_windows, d_cls, mags,
+                              bins, (unsigned long long *)ws, st);
+    if (rc == WN_OK && !capturing) {
+        WN_HIP_TRY(hipEventRecord(g_noalloc_event[ctx->device], st));
+        g_noalloc_recorded[ctx->device] = true;
+    }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -254,49 +254,47 @@ __device__ __forceinline__ void synth_body(
         }
         if (!SINE_GLOBAL && (long long)total < (long long)ns * (16 * BLOCK)) {
             // Short segments (fewer than four steps of the workgroup each, as in the prototype
-            // scheme): going segment by segment would leave most lanes idle, so the threads
-            // walk the part as one run of vectors, each keeping its own current segment.
-            int lo = sg < ns ? s_start[sg] : total;
-            int hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
-            int fq = sg < ns ? s_freq[sg] : 0;
-            const int head = (4 - ((mis + p0) & 3)) & 3;        // samples before the first aligned vector
-            for (int p = p0 - ((4 - head) & 3) + 4 * tid; p < p1; p += 4 * BLOCK) {
-                const int q0 = p < p0 ? p0 : p;                 // the first vector may start before the part
-                const int q1 = p + 4 < p1 ? p + 4 : p1;
-                while (q0 >= hi) {
-                    ++sg;
-                    lo = hi;
-                    hi = sg < ns ? s_start[sg + 1] : 0x7fffffff;
-                    fq = sg < ns ? s_freq[sg] : 0;
-                }
-                if (q0 == p && q1 == p + 4 && (sg >= ns || p + 3 < hi)) {   // a whole vector inside one segment
-                    V4 o = {};
-                    if (sg < ns) {
-                        int m = mod_sr((unsigned)fq * (unsigned)(p - lo), sr, inv_sr);
+            // scheme): going segment by segment with the whole workgroup would leave most lanes
+            // idle, so each wave takes a segment of its own (every BLOCK/64-th one of the part):
+            // the segment's bounds and frequency are the same in all its lanes, a lane keeps its
+            // phase and advances it by the wave's step of 256 samples, and the samples come
+            // straight from the quarter-wave table.
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int g = sg + wave; g < ns; g += BLOCK / 64) {
+                const int lo = s_start[g], hi = s_start[g + 1];
+                if (lo >= p1) break;
+                const int a = lo > p0 ? lo : p0, b = hi < p1 ? hi : p1;
+                const int fq = s_freq[g];
+                int va = a + ((4 - ((mis + a) & 3)) & 3);    // first aligned vector of the segment
+                va = va > b ? b : va;
+                const int vb = va + ((b - va) & ~3);         // end of the last one
+                int v = va + 4 * lane;
+                if (v < vb) {
+                    int m = mod_sr((unsigned)fq * (unsigned)(v - lo), sr, inv_sr);
+                    const int mstep = mod_sr((unsigned)fq * 256u, sr, inv_sr);
+                    for (; v < vb; v += 256) {
+                        int mk = m;
                         T e[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            e[k] = sine(m);
-                            m += fq;
-                            m = m >= sr ? m - sr : m;
+                            e[k] = sine(mk);
+                            mk += fq;
+                            mk = mk >= sr ? mk - sr : mk;
                         }
+                        V4 o;
                         o.x = e[0]; o.y = e[1]; o.z = e[2]; o.w = e[3];
-                    }
-                    *(V4 *)(out + p) = o;
-                } else {                                         // a boundary inside: sample by sample
-                    int sl = sg, ll = lo, hl = hi, fl = fq;
-                    for (int q = q0; q < q1; ++q) {
-                        while (q >= hl) {
-                            ++sl;
-                            ll = hl;
-                            hl = sl < ns ? s_start[sl + 1] : 0x7fffffff;
-                            fl = sl < ns ? s_freq[sl] : 0;
-                        }
-                        out[q] = sl < ns ? sine(mod_sr((unsigned)fl * (unsigned)(q - ll), sr, inv_sr)) : (T)0;
+                        *(V4 *)(out + v) = o;
+                        m += mstep;
+                        m = m >= sr ? m - sr : m;
                     }
                 }
+                if (lane < 8) {                 // up to three samples before va and after vb
+                    const int pos = lane < 4 ? a + lane : vb + (lane - 4);
+                    const int lim = lane < 4 ? va : b;
+                    if (pos < lim) out[pos] = sine(mod_sr((unsigned)fq * (unsigned)(pos - lo), sr, inv_sr));
+                }
             }
-            continue;
+            sg = ns;   // nothing left for the segment loop below; the zero fill follows it
         }
         // a table pays when the segment is several periods long; otherwise straight from the
         // quarter-wave table
@@ -414,6 +412,51 @@ __global__ __launch_bounds__(SYN_LEAN_BLOCK) __attribute__((amdgpu_num_vgpr(40))
 }
 
 // ---------------------------------------------------------------------------------------
+// Sines computed on the GPU against the table the host built: one thread per table entry, both
+// output formats.  Used once when a context is made (wn_synth_sines_agree).
+// ---------------------------------------------------------------------------------------
+__global__ void sine_check_kernel(const float *__restrict__ tab_f, const int16_t *__restrict__ tab_h, int quarter,
+                                  double amp, double gain, double w_unit, unsigned *__restrict__ mismatches) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m > quarter) return;
+    const double sn = sin_quarter(m, quarter, w_unit);
+    double w = amp * sn;
+    if (gain != 1.0) {
+        w = w * gain;
+        w = w < -1.0 ? -1.0 : (w > 1.0 ? 1.0 : w);
+    }
+    const float f = (float)w;
+    const int16_t h = (int16_t)(amp * sn * 32767.0);
+    if (f != tab_f[m] || h != tab_h[m]) atomicAdd(mismatches, 1u);
+}
+
+// WN_OK with *agree set: whether every sine the synthesis kernel would compute for this scheme (its
+// sample rate, amplitude and gain) equals, after rounding to float32 and to int16, the entry of
+// the quarter-wave table the host built with sin().  The tests pin that for the shipped schemes;
+// for any other scheme this check decides at run time, and a context whose sines do not all agree
+// takes its samples from the table instead (synth_table_lds).
+int wn_synth_sines_agree(wn_ctx *ctx, bool *agree) {
+    unsigned *d = nullptr, h = 0;
+    WN_HIP_TRY(hipMalloc((void **)&d, sizeof(unsigned)));
+    hipError_t e = hipMemset(d, 0, sizeof(unsigned));
+    if (e == hipSuccess) {
+        const int n = ctx->quarter + 1;
+        hipLaunchKernelGGL(sine_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ctx->d_sin_f32,
+                           ctx->d_sin_i16, ctx->quarter, ctx->s.amp, ctx->s.gain,
+                           2.0 * M_PI / (double)ctx->s.sample_rate, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        wn_set_error("sine check failed: %s", hipGetErrorString(e));
+        return WN_ERR_HIP;
+    }
+    *agree = h == 0;
+    return WN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // Channel noise: sample i gets sigma * z(seed, i), z from splitmix64 bits by Box-Muller.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -508,7 +551,9 @@ extern "C" int wn_synth_batch(wn_ctx *ctx, const int32_t *d_seg_start, const uin
     // WN_SYNTH_PART / WN_SYNTH_PER_CU (workgroups per CU of the grid) override the choice for tuning.
     const long long resident = (long long)ctx->num_cus * (tab_lds ? 2 : 4);
     long long part_want = (n * slot_len / (resident * 4) + 4095) & ~4095ll;
-    const long long part_max = tab_lds ? 196608 : 49152;   // a workgroup with the table in LDS loads 44 KB first: fewer, larger parts
+    // a workgroup with the table in LDS loads 44 KB first: larger parts (20 000 prototype-scheme messages of
+    // 282 240 samples: 4.54 ms at parts of 70 560, 4.73-4.83 at 35 280, 141 120 and 282 240)
+    const long long part_max = tab_lds ? 73728 : 49152;
     part_want = part_want < 16384 ? 16384 : (part_want > part_max ? part_max : part_want);
     if (ctx->synth_part >= 4096) part_want = ctx->synth_part;
     long long parts = (slot_len + part_want - 1) / part_want;
