@@ -239,7 +239,7 @@ def noisy_detection(m, audio, n_streams, stride, nwin):
     m.awgn(audio, 0.1, 99)
     m.detect_stats()
     ms = timed_launches(lambda: m.detect(audio, n_streams, stride, nwin))
-    w, top2, full, cells, units, redone, whole = m.detect_stats(paths=True)
+    w, top2, full, cells, units, redone, whole, two = m.detect_stats(paths=True)
     cls, _, _ = m.detect(audio, n_streams, stride, nwin)
     by, ln, _, _, reason, _ = m.slice(cls, m.timeout_windows(123.0), 1, 128)
     rec = m.parse_frames(by.view(n_streams, 128), ln.view(-1)).cpu().numpy().view(M.REC_DTYPE).reshape(-1)
@@ -249,7 +249,8 @@ def noisy_detection(m, audio, n_streams, stride, nwin):
             "hbm_frac": n_streams * nwin * (WIN * 4 + 10) / ms / 1e6 / 8000.0,
             "stage1_tile_columns_computed_per_window": units / max(w, 1),
             "stage2_tile_columns_computed_per_window": cells / max(w, 1),
-            "share_of_windows_on_every_column_tile": whole / max(w, 1), "windows_done_twice": redone / max(w, 1),
+            "passes_the_long_way_per_window": whole / max(w, 1), "of_them_without_the_weakest_column_tile": two / max(w, 1),
+            "windows_done_twice": redone / max(w, 1),
             "float64_two_or_three_bins_per_window": top2 / max(w, 1), "float64_whole_spectrum_per_window": full / max(w, 1),
             "frames_valid": ok, "frames": n_streams}
 
@@ -500,7 +501,7 @@ def main():
         win_per_launch = sub * nwin
         # flop of what the launches computed: stage 1 of every window, stage 2 of the spectrum
         # columns the kernel did not leave out (counted by the kernel itself over the timed steps)
-        st_windows, _, _, st_cells, st_units, st_redone, st_whole = counters
+        st_windows, _, _, st_cells, st_units, st_redone, st_whole, st_two = counters
         s1_flop_per_unit, s1_units_full, s2_flop_per_unit, s2_units_full = detect_flop(n1, n2)
         cells_per_window = st_cells / max(st_windows, 1)
         units_per_window = st_units / max(st_windows, 1)
@@ -550,7 +551,8 @@ def main():
                          "stage2_tile_columns_per_window": s2_units_full,
                          "stage1_tile_columns_computed_per_window": units_per_window,
                          "stage1_tile_columns_per_window": s1_units_full,
-                         "share_of_windows_on_every_column_tile": st_whole / max(st_windows, 1),
+                         "passes_the_long_way_per_window": st_whole / max(st_windows, 1),
+                         "of_them_without_the_weakest_column_tile": st_two / max(st_windows, 1),
                          "windows_done_twice": st_redone / max(st_windows, 1)},
             "synth": {"bound": "hbm", "kernel": "synth_kernel<float, false>", "ms_per_launch": syn_ms,
                       "algorithmic_bytes": sub * stride * 4,

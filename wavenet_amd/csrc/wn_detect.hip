@@ -178,6 +178,39 @@ __device__ __forceinline__ void mfma1_acc(floatx4 &y, float a, float b_acc) {
 __device__ __forceinline__ void mfma1_new(floatx4 &y, float a, float b_acc) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(y) : "v"(a), "a"(b_acc));
 }
+// declares an accumulation register written (no instruction): the statements below update it in place
+__device__ __forceinline__ void acc_declare(floatx4 &y) { asm volatile("" : "=a"(y)); }
+// One k-step of stage 1 for one column tile (six row tiles, real and imaginary part: twelve matrix
+// instructions), skipped as a whole when bit BIT of `need` is clear.  The branch sits inside the
+// one asm statement: to the compiler the accumulation registers are updated in place whatever
+// happens, so it has nothing to copy where the two ways meet (the same instructions under an
+// `if` of the source made it spill over a hundred registers).
+template <bool FIRST, int BIT>
+__device__ __forceinline__ void mfma1_tile_if(unsigned need, floatx4 (&yr)[6], floatx4 (&yi)[6], const float (&as)[6],
+                                              const float (&ad)[6], float tc_acc, float ts_acc) {
+#define WN_T(I, Y, A, B) "v_mfma_f32_16x16x4_f32 %" #Y ", %" #A ", %" #B ", " I "\n\t"
+    if constexpr (FIRST)
+        asm volatile("s_bitcmp1_b32 %26, %27\n\ts_cbranch_scc0 9f\n\t"
+                     WN_T("0", 0, 12, 24) WN_T("0", 6, 18, 25) WN_T("0", 1, 13, 24) WN_T("0", 7, 19, 25)
+                     WN_T("0", 2, 14, 24) WN_T("0", 8, 20, 25) WN_T("0", 3, 15, 24) WN_T("0", 9, 21, 25)
+                     WN_T("0", 4, 16, 24) WN_T("0", 10, 22, 25) WN_T("0", 5, 17, 24) WN_T("0", 11, 23, 25) "9:"
+                     : "+a"(yr[0]), "+a"(yr[1]), "+a"(yr[2]), "+a"(yr[3]), "+a"(yr[4]), "+a"(yr[5]), "+a"(yi[0]),
+                       "+a"(yi[1]), "+a"(yi[2]), "+a"(yi[3]), "+a"(yi[4]), "+a"(yi[5])
+                     : "v"(as[0]), "v"(as[1]), "v"(as[2]), "v"(as[3]), "v"(as[4]), "v"(as[5]), "v"(ad[0]), "v"(ad[1]),
+                       "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "a"(tc_acc), "a"(ts_acc), "s"(need), "n"(BIT)
+                     : "scc");
+    else
+        asm volatile("s_bitcmp1_b32 %26, %27\n\ts_cbranch_scc0 9f\n\t"
+                     WN_T("%0", 0, 12, 24) WN_T("%6", 6, 18, 25) WN_T("%1", 1, 13, 24) WN_T("%7", 7, 19, 25)
+                     WN_T("%2", 2, 14, 24) WN_T("%8", 8, 20, 25) WN_T("%3", 3, 15, 24) WN_T("%9", 9, 21, 25)
+                     WN_T("%4", 4, 16, 24) WN_T("%10", 10, 22, 25) WN_T("%5", 5, 17, 24) WN_T("%11", 11, 23, 25) "9:"
+                     : "+a"(yr[0]), "+a"(yr[1]), "+a"(yr[2]), "+a"(yr[3]), "+a"(yr[4]), "+a"(yr[5]), "+a"(yi[0]),
+                       "+a"(yi[1]), "+a"(yi[2]), "+a"(yi[3]), "+a"(yi[4]), "+a"(yi[5])
+                     : "v"(as[0]), "v"(as[1]), "v"(as[2]), "v"(as[3]), "v"(as[4]), "v"(as[5]), "v"(ad[0]), "v"(ad[1]),
+                       "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "a"(tc_acc), "a"(ts_acc), "s"(need), "n"(BIT)
+                     : "scc");
+#undef WN_T
+}
 __device__ __forceinline__ void mfma2_acc(floatx4 &acc, float a, float b_acc) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_acc));
 }
@@ -264,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                                                         long long n_windows, const float2 *__restrict__ g_tw1,
                                                         const float2 *__restrict__ g_tw2,
                                                         const uint16_t *__restrict__ lut, float keep,
-                                                        float err_lin, float err_sq, float one_share,
+                                                        float err_lin, float err_sq, float one_share, float two_share,
                                                         uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
                                                         int32_t *__restrict__ out_bin,
                                                         unsigned long long *__restrict__ stats) {
@@ -376,14 +409,16 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     // come Z[k1][k2] (side 0) and Z[n1-k1][k2] (side 1).  The bin of Z[j][k2] is
     // (j*E1 + k2*E2) mod N folded to [0, N/2].  Padding rows and columns (whose sums are
     // exactly zero) carry the bin field alone; the bin the reference never looks at and the
-    // second copy of self-mirrored outputs (k1 = 0 or k2 = 0) are marked unused.
-    unsigned tag[TA][4][C2T][2];
+    // second copy of self-mirrored outputs (k1 = 0 or k2 = 0) are marked unused.  The two sides of
+    // an element share a register: plus side in the low half, minus side in the high half.
+    unsigned tag[TA][4][C2T];
 #pragma unroll
     for (int t = 0; t < TA; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < C2T; ++c)
+            for (int c = 0; c < C2T; ++c) {
+                unsigned both = 0u;
 #pragma unroll
                 for (int sg = 0; sg < 2; ++sg) {
                     const int k1 = 16 * t + 4 * lg + r, k2 = 16 * c + li;
@@ -392,8 +427,10 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     const int kk = min(kb, N - kb);
                     const bool ok = (k1 <= H1) & (k2 <= H2) & (kk < N / 2) & (!sg | ((k1 != 0) & (k2 != 0)));
                     const bool pad = (k1 > H1) | (k2 > H2);
-                    tag[t][r][c][sg] = ok ? (unsigned)kk : (pad ? KEY_BIN : (EP_UNUSED | KEY_BIN));
+                    both |= (ok ? (unsigned)kk : (pad ? KEY_BIN : (EP_UNUSED | KEY_BIN))) << (16 * sg);
                 }
+                tag[t][r][c] = both;
+            }
 
     // ---- window staging by LDS-DMA
     auto fetch = [&](long long s, long long wi) {
@@ -506,7 +543,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
 
     unsigned long long s1_units = 0;    // (row tile, real or imaginary part, column) products of stage 1 this wave computed (statistics)
     unsigned long long redone = 0;      // windows done a second time, the whole way
-    unsigned long long whole_n = 0;     // windows that took the whole-spectrum way (those done twice included)
+    unsigned long long whole_n = 0;     // passes the long way (windows done twice included)
+    unsigned long long two_n = 0;       // of them: with one column tile left out
     int next_off = 0;
     if (w < total) {
         next_off = fetch(f_s, f_w);
@@ -546,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // (Doing the k-steps in pairs, for half as many changes between matrix and vector work, was
         // slower: 24 LDS reads in one go exceed the 15 the wave may have outstanding.)
         constexpr int WHOLE = 1, ONE = 2;
-        auto stage1 = [&](auto CUT_, auto CSEL_) {
+        auto stage1 = [&](auto CUT_, auto CSEL_, unsigned need) {   // need (WHOLE only): the column tiles to compute, wave-uniform
             constexpr int CUT = decltype(CUT_)::value, CSEL = decltype(CSEL_)::value;
             // row-tile pairs gathered here: all of them, or all but pair 0 when the pilot kept its operands
             constexpr int P0 = WN_DETECT_KEEP0 ? 1 : 0, NP = TA - P0;
@@ -585,6 +623,14 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     asm volatile("" : "+v"(e4[t]), "+v"(sx[t]));
                 });
             };
+            if constexpr (CUT == WHOLE && C2T > 2) {
+                static_for<C2T>([&](auto C) {
+                    static_for<T1>([&](auto T) {
+                        acc_declare(Yr[decltype(C)::value][decltype(T)::value]);
+                        acc_declare(Yi[decltype(C)::value][decltype(T)::value]);
+                    });
+                });
+            }
             rd(ic<0>{});
             __builtin_amdgcn_sched_barrier(0);
             fold(ic<0>{});
@@ -594,25 +640,44 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             static_for<KS1>([&](auto KS) {
                 constexpr int ks = decltype(KS)::value;
                 static_for<C2T>([&](auto C) {
-                    static_for<T1>([&](auto T) {
-                        constexpr int c = decltype(C)::value, t = decltype(T)::value;
-                        constexpr bool mine = CUT == WHOLE || c == CSEL;
-                        // position of this pair of matrix instructions in the k-step
-                        constexpr int idx = CUT == ONE ? t : c * T1 + t;
-                        if constexpr (mine) {
+                    constexpr int c = decltype(C)::value;
+                    auto tile = [&]() {
+                        static_for<T1>([&](auto T) {
+                            constexpr int t = decltype(T)::value;
                             // row-tile pair 0 takes the operands the pilot folded and kept
                             const float as = (WN_DETECT_KEEP0 && t % TA == 0) ? xs0[ks][t / TA] : xs[t % TA][t / TA];
                             const float ad = (WN_DETECT_KEEP0 && t % TA == 0) ? xd0[ks][t / TA] : xd[t % TA][t / TA];
                             if constexpr (ks == 0) mfma1_new(Yr[c][t], as, t2c[ks][c]);
                             else mfma1_acc(Yr[c][t], as, t2c[ks][c]);
-                            rd1(ic<ks + 2>{}, ic<2 * idx>{});
+                            // the sample reads of k-step ks+2 ride on the first matrix instructions of a
+                            // column tile; every tile that runs issues them (the same values again:
+                            // which tiles run is not known when the code is laid out)
+                            rd1(ic<ks + 2>{}, ic<2 * t>{});
                             __builtin_amdgcn_sched_barrier(0);
                             if constexpr (ks == 0) mfma1_new(Yi[c][t], ad, t2s[ks][c]);
                             else mfma1_acc(Yi[c][t], ad, t2s[ks][c]);
-                            rd1(ic<ks + 2>{}, ic<2 * idx + 1>{});
+                            rd1(ic<ks + 2>{}, ic<2 * t + 1>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                    };
+                    if constexpr (CUT == WHOLE && C2T > 2) {
+                        if constexpr (T1 == 6) {
+                            float asv[6], adv[6];
+                            static_for<6>([&](auto T) {
+                                constexpr int t = decltype(T)::value;
+                                asv[t] = (WN_DETECT_KEEP0 && t % TA == 0) ? xs0[ks][t / TA] : xs[t % TA][t / TA];
+                                adv[t] = (WN_DETECT_KEEP0 && t % TA == 0) ? xd0[ks][t / TA] : xd[t % TA][t / TA];
+                            });
+                            mfma1_tile_if<ks == 0, c>(need, Yr[c], Yi[c], asv, adv, t2c[ks][c], t2s[ks][c]);
+                            // the sample reads of k-step ks+2, a third of them behind each tile
+                            static_for<4 * NP>([&](auto M) {
+                                if constexpr (decltype(M)::value % C2T == c) rd1(ic<ks + 2>{}, M);
+                            });
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                    });
+                    } else if constexpr (CUT == WHOLE || c == CSEL) {
+                        tile();
+                    }
                 });
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ks + 1 < KS1) {
@@ -847,15 +912,18 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                         static_for<2>([&](auto EL) {
                             constexpr int r = 2 * hf + decltype(EL)::value;
                             float mp = mp2[decltype(EL)::value], mm = mm2[decltype(EL)::value];
-                            const unsigned tp = tag[tt][r][c][0], tm = tag[tt][r][c][1];
+                            // (the empty statement keeps the two halves from being taken apart once and for
+                            // all ahead of the window loop, which would cost the registers the packing saves)
+                            asm volatile("" : "+v"(tag[tt][r][c]));
+                            const unsigned tp = tag[tt][r][c], tm = tp >> 16;   // only the low 12 bits (and bit 15) of each are used
                             // outputs that must not compete although their value is not zero: known positions
                             constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
                             if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
                             if constexpr (c == 0 || (tt == 0 && r == 0) || (xhere && P::XMINUS))
                                 mm = __builtin_unpredictable(tm & EP_UNUSED) ? 0.f : mm;
                             best.mx = max(best.mx, max(__float_as_uint(mp), __float_as_uint(mm)));
-                            top3_insert(best, (__float_as_uint(mp) & ~KEY_BIN) | tp);
-                            top3_insert(best, (__float_as_uint(mm) & ~KEY_BIN) | tm);
+                            top3_insert(best, (__float_as_uint(mp) & ~KEY_BIN) | (tp & KEY_BIN));
+                            top3_insert(best, (__float_as_uint(mm) & ~KEY_BIN) | (tm & KEY_BIN));
                         });
                     });
                     // each bin once: where k2 = 0 (column tile 0, li = 0) every minus-side output repeats
@@ -897,20 +965,50 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             best.mx = 0u;
             eproc = 0.f;
         };
+        constexpr unsigned ALL = (1u << C2T) - 1u;
         bool whole = !one_tile;
+        // Column tiles whose stage 1 the long way computes.  With three column tiles, a window whose
+        // pilot finds next to nothing in the weakest one (a tone meeting the separator, each in its
+        // own tile) does without that tile; should the check still fail after the other two, the
+        // window is done again with all three.
+        unsigned need = ALL;
+        if constexpr (C2T > 2) {
+            if (!one_tile) {
+                int c_min = 0;
+                unsigned low = eo[0];
+                float tot = __uint_as_float(eo[0]);
+#pragma unroll
+                for (int c = 1; c < C2T; ++c) {
+                    tot += __uint_as_float(eo[c]);
+                    if (eo[c] < low) {
+                        low = eo[c];
+                        c_min = c;
+                    }
+                }
+                if (__uint_as_float(low) <= two_share * tot && tot <= 1e30f) need = ALL & ~(1u << c_min);
+            }
+        }
+        auto refetch = [&]() {
+            // The window's buffer is by now being overwritten by the next window: wait for that
+            // DMA, fetch this window again (the long way then fetches the next window again).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            (void)fetch(cur_s, cur_w);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ++redone;
+        };
         if (one_tile) {
             // the pilot found the energy in one column tile: stage 1 and stage 2 of that tile only
             bool done = false;
             if (c_first == 0) {
-                stage1(ic<ONE>{}, ic<0>{});
+                stage1(ic<ONE>{}, ic<0>{}, 0u);
                 after_stage1(ic<1>{});
                 done = col_tile(ic<0>{}, true, ic<1>{});
             } else if (c_first == 1) {
-                stage1(ic<ONE>{}, ic<1>{});
+                stage1(ic<ONE>{}, ic<1>{}, 0u);
                 after_stage1(ic<1>{});
                 done = col_tile(ic<1>{}, true, ic<1>{});
             } else if constexpr (C2T > 2) {
-                stage1(ic<ONE>{}, ic<2>{});
+                stage1(ic<ONE>{}, ic<2>{}, 0u);
                 after_stage1(ic<1>{});
                 done = col_tile(ic<2>{}, true, ic<1>{});
             }
@@ -918,33 +1016,30 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             s1_units += (unsigned)(OTHER_TILES * ncol);
             if (!done) {
                 // Other column tiles are needed after all (energy in one column tile, but spread
-                // over many bins: rare).  The window's buffer is by now being overwritten by the
-                // next window: wait for that DMA, fetch this window again and do it the whole way
-                // (which fetches the next window again).
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                (void)fetch(cur_s, cur_w);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // over many bins: rare): the whole way.
+                refetch();
                 whole = true;
-                ++redone;
             }
         }
-        if (whole) {
-            // every column tile gets its stage 1; stage 2 takes the one with the largest rough
-            // energy first (any order is valid; this one ends the loop soonest) and chooses again
-            // among the rest each time it has to go on
-            stage1(ic<WHOLE>{}, ic<0>{});
-            s1_units += OTHER_TILES * P::K2;
+        while (whole) {
+            // the column tiles in `need` get their stage 1; stage 2 takes the one with the largest
+            // rough energy first (any order is valid; this one ends the loop soonest) and chooses
+            // again among the rest each time it has to go on
+            stage1(ic<WHOLE>{}, ic<0>{}, need);
+#pragma unroll
+            for (int c = 0; c < C2T; ++c)
+                if (need & (1u << c)) s1_units += (unsigned)(OTHER_TILES * NCOL[c]);
             ++whole_n;
+            if (need != ALL) ++two_n;
             after_stage1(ic<0>{});
             have_max = false;
-            unsigned todo = (1u << C2T) - 1u;
+            unsigned todo = need;
+            bool done = false;
 #pragma nounroll
-            for (int i = 0; i < C2T; ++i) {
+            for (int i = 0; todo != 0u; ++i) {
                 int c;
                 if (i == 0) {
                     c = c_first;
-                } else if (i == C2T - 1) {
-                    c = __ffs((int)todo) - 1;
                 } else {
                     unsigned key = 0u;   // energy bits, tile number in the low bits
 #pragma unroll
@@ -953,13 +1048,17 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     c = (int)(key & 3u);
                 }
                 todo &= ~(1u << c);
-                const bool more = i + 1 < C2T;
-                bool done = false;
+                // after the very last row tile of a window there is nothing left to rule out; tiles
+                // that were left out still have to be
+                const bool more = todo != 0u || need != ALL;
                 if (c == 0) done = col_tile(ic<0>{}, more, ic<0>{});
                 else if (c == 1) done = col_tile(ic<1>{}, more, ic<0>{});
                 else if constexpr (C2T > 2) done = col_tile(ic<2>{}, more, ic<0>{});
                 if (done) break;
             }
+            if (done || need == ALL) break;
+            refetch();      // the tile that was left out is needed after all
+            need = ALL;
         }
         lap(ic<3>{});
         if (wn < total) advance();
@@ -1032,6 +1131,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         atomicAdd(&stats[4], s1_units);
         if (redone) atomicAdd(&stats[5], redone);
         if (whole_n) atomicAdd(&stats[6], whole_n);
+        if (two_n) atomicAdd(&stats[7], two_n);
     }
     if constexpr (PROF) {
         // out_bin[0..6]: clocks/256 per phase (DMA wait, pilot of stage 1 and the column tiles' rough
@@ -1282,12 +1382,12 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     if (ctx->detect_profile && total >= 16 + 4 * blocks)
         hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
-                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share,
+                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
                            d_cls, d_mag, d_bin, stats);
     else
         hipLaunchKernelGGL((detect_kernel<N1, N2, false>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
-                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share,
+                           (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
                            d_cls, d_mag, d_bin, stats);
     return wn_launch_check("detect_kernel");
 }
