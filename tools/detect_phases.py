@@ -45,3 +45,8 @@ for what, audio in (("noise", 0.3 * torch.randn((S, stride), device="cuda")), ("
     t = mag.view(-1)[16:16 + 1024].double() * 1e-5   # ms
     print("  waves ran %.3f / %.3f / %.3f ms (min / mean / max): the launch waits %.2f %% for its slowest wave"
           % (t.min().item(), t.mean().item(), t.max().item(), 100.0 * (t.max().item() / t.mean().item() - 1.0)))
+    wg = t.view(-1, 4)[:256]
+    print("  mean by workgroup index mod 8 (ms): " + " ".join("%.3f" % wg[i::8].mean().item() for i in range(8)))
+    print("  spread inside a workgroup (max - min of its four waves, mean over workgroups): %.3f ms; slowest workgroups: %s"
+          % ((wg.max(1).values - wg.min(1).values).mean().item(),
+             ", ".join("%d (%.3f)" % (i, wg[i].max().item()) for i in wg.max(1).values.argsort(descending=True)[:6].tolist())))

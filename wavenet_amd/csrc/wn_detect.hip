@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                                                      long long n_windows, int N, int n1, int n2, int e1, int e2,
                                                      const uint16_t *__restrict__ lut,
                                                      uint16_t *__restrict__ cls, float *__restrict__ mag,
-                                                     int32_t *__restrict__ bin, unsigned long long *stats) {
+                                                     int32_t *__restrict__ bin, unsigned long long *stats, int chunk) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // pass 0: exp(2*pi*i*j/N), j < 128, then exp(2*pi*i*128*k/N), k < ceil(N/128)
     double2 *tab_lo = (double2 *)smem, *tab_hi = tab_lo + 128;
@@ -1205,9 +1205,11 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
         const double2 h = tab_hi[m >> 7], l = tab_lo[m & 127];
         return make_double2(h.x * l.x - h.y * l.y, h.x * l.y + h.y * l.x);
     };
-    for (long long base = (long long)blockIdx.x * 256; base < total; base += (long long)gridDim.x * 256) {
+    // a workgroup takes `chunk` windows (64 or 256) at a time: small launches use the small chunk so that
+    // their flagged windows, which a workgroup re-evaluates one after the other, spread over more CUs
+    for (long long base = (long long)blockIdx.x * chunk; base < total; base += (long long)gridDim.x * chunk) {
         const long long idx = base + tid;
-        int fl = idx < total ? (bin[idx] & FLAG_MASK) : 0;
+        int fl = (tid < chunk && idx < total) ? (bin[idx] & FLAG_MASK) : 0;
         if constexpr (PASS == 1) fl &= FLAG_FULL;
         if (!__syncthreads_or(fl)) continue;
         // flagged windows of this chunk, one bit per thread
@@ -1215,7 +1217,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
         __syncthreads();
         if (lane == 0) flagged[wave] = bal;
         __syncthreads();
-        for (int fw = 0; fw < 4; ++fw)
+        for (int fw = 0; fw < chunk / 64; ++fw)
         for (unsigned long long mask = flagged[fw]; mask; mask &= mask - 1) {
             const long long wi = base + 64 * fw + __ffsll((long long)mask) - 1;
             const int f = bin[wi];  // same address in every thread
@@ -1233,19 +1235,30 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                 const unsigned uN = (unsigned)N;
                 unsigned m1 = (unsigned)(b1 * tid) % uN, m2 = (unsigned)(b2 * tid) % uN, m3 = (unsigned)(b3 * tid) % uN;
                 const unsigned d1 = (unsigned)(b1 * 256) % uN, d2 = (unsigned)(b2 * 256) % uN, d3 = (unsigned)(b3 * 256) % uN;
-                for (int n = tid; n < N; n += 256) {
-                    const double xv = (double)x[n];
-                    const double2 t1 = phase(m1);
-                    const double2 t2 = phase(m2);
-                    r1 += xv * t1.x; i1 += xv * t1.y;
-                    r2 += xv * t2.x; i2 += xv * t2.y;
-                    if (three) {
-                        const double2 t3 = phase(m3);
-                        r3 += xv * t3.x; i3 += xv * t3.y;
-                        m3 += d3; m3 = m3 >= uN ? m3 - uN : m3;
+                // sixteen samples per thread are requested before the first is used: one trip to memory
+                // per sixteen instead of one per sample
+                for (int n0 = tid; n0 < N; n0 += 256 * 16) {
+                    float xq[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int n = n0 + 256 * q;
+                        xq[q] = n < N ? x[n] : 0.f;
                     }
-                    m1 += d1; m1 = m1 >= uN ? m1 - uN : m1;
-                    m2 += d2; m2 = m2 >= uN ? m2 - uN : m2;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const double xv = (double)xq[q];
+                        const double2 t1 = phase(m1);
+                        const double2 t2 = phase(m2);
+                        r1 += xv * t1.x; i1 += xv * t1.y;
+                        r2 += xv * t2.x; i2 += xv * t2.y;
+                        if (three) {
+                            const double2 t3 = phase(m3);
+                            r3 += xv * t3.x; i3 += xv * t3.y;
+                            m3 += d3; m3 = m3 >= uN ? m3 - uN : m3;
+                        }
+                        m1 += d1; m1 = m1 >= uN ? m1 - uN : m1;
+                        m2 += d2; m2 = m2 >= uN ? m2 - uN : m2;
+                    }
                 }
                 r1 = wave_sum(r1); i1 = wave_sum(i1); r2 = wave_sum(r2); i2 = wave_sum(i2);
                 r3 = wave_sum(r3); i3 = wave_sum(i3);
@@ -1460,19 +1473,20 @@ static int detect_run(wn_ctx *ctx, const float *d_audio, int64_t audio_len, int6
     }
     if (rc != WN_OK) return rc;
     const long long total = n_streams * n_windows;
-    const long long chunks = (total + 255) / 256;
+    const int chunk = total < (long long)ctx->num_cus * 8 * 256 ? 64 : 256;
+    const long long chunks = (total + chunk - 1) / chunk;
     const long long b0 = chunks < (long long)ctx->num_cus * 8 ? chunks : (long long)ctx->num_cus * 8;
     const long long b1 = chunks < (long long)ctx->num_cus * 2 ? chunks : (long long)ctx->num_cus * 2;
     const size_t lds0 = (size_t)(128 + (ctx->n + 127) / 128) * sizeof(double2);
     const size_t lds1 = (size_t)(ctx->n1 * (ctx->n2 / 2 + 1) + ctx->n1 + ctx->n2) * sizeof(double2);
     hipLaunchKernelGGL(refine_kernel<0>, dim3((unsigned)b0), dim3(256), lds0, st, d_audio, (long long)n_streams,
                        (long long)stream_stride, (long long)first_sample, (long long)n_windows, ctx->n, ctx->n1, ctx->n2,
-                       ctx->e1, ctx->e2, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats);
+                       ctx->e1, ctx->e2, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats, chunk);
     rc = wn_launch_check("refine_kernel<0>");
     if (rc != WN_OK) return rc;
     hipLaunchKernelGGL(refine_kernel<1>, dim3((unsigned)b1), dim3(256), lds1, st, d_audio, (long long)n_streams,
                        (long long)stream_stride, (long long)first_sample, (long long)n_windows, ctx->n, ctx->n1, ctx->n2,
-                       ctx->e1, ctx->e2, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats);
+                       ctx->e1, ctx->e2, ctx->d_cls_lut, d_cls, d_mag, d_bin, stats, chunk);
     return wn_launch_check("refine_kernel");
 }
 
