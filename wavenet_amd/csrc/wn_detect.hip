@@ -1235,30 +1235,20 @@ __global__ __launch_bounds__(256) void refine_kernel(const float *__restrict__ a
                 const unsigned uN = (unsigned)N;
                 unsigned m1 = (unsigned)(b1 * tid) % uN, m2 = (unsigned)(b2 * tid) % uN, m3 = (unsigned)(b3 * tid) % uN;
                 const unsigned d1 = (unsigned)(b1 * 256) % uN, d2 = (unsigned)(b2 * 256) % uN, d3 = (unsigned)(b3 * 256) % uN;
-                // sixteen samples per thread are requested before the first is used: one trip to memory
-                // per sixteen instead of one per sample
-                for (int n0 = tid; n0 < N; n0 += 256 * 16) {
-                    float xq[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int n = n0 + 256 * q;
-                        xq[q] = n < N ? x[n] : 0.f;
+#pragma unroll 2
+                for (int n = tid; n < N; n += 256) {
+                    const double xv = (double)x[n];
+                    const double2 t1 = phase(m1);
+                    const double2 t2 = phase(m2);
+                    r1 += xv * t1.x; i1 += xv * t1.y;
+                    r2 += xv * t2.x; i2 += xv * t2.y;
+                    if (three) {
+                        const double2 t3 = phase(m3);
+                        r3 += xv * t3.x; i3 += xv * t3.y;
+                        m3 += d3; m3 = m3 >= uN ? m3 - uN : m3;
                     }
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const double xv = (double)xq[q];
-                        const double2 t1 = phase(m1);
-                        const double2 t2 = phase(m2);
-                        r1 += xv * t1.x; i1 += xv * t1.y;
-                        r2 += xv * t2.x; i2 += xv * t2.y;
-                        if (three) {
-                            const double2 t3 = phase(m3);
-                            r3 += xv * t3.x; i3 += xv * t3.y;
-                            m3 += d3; m3 = m3 >= uN ? m3 - uN : m3;
-                        }
-                        m1 += d1; m1 = m1 >= uN ? m1 - uN : m1;
-                        m2 += d2; m2 = m2 >= uN ? m2 - uN : m2;
-                    }
+                    m1 += d1; m1 = m1 >= uN ? m1 - uN : m1;
+                    m2 += d2; m2 = m2 >= uN ? m2 - uN : m2;
                 }
                 r1 = wave_sum(r1); i1 = wave_sum(i1); r2 = wave_sum(r2); i2 = wave_sum(i2);
                 r3 = wave_sum(r3); i3 = wave_sum(i3);
