@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // window is done again with all three.
         unsigned need = ALL;
         if constexpr (C2T > 2) {
-            if (!one_tile) {
+            {   // (also for a window that starts on one tile: should its check fail, the long way follows)
                 int c_min = 0;
                 unsigned low = eo[0];
                 float tot = __uint_as_float(eo[0]);
