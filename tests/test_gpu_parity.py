@@ -565,6 +565,52 @@ def test_detect_windows_done_twice(mb, golden):
         assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
 
 
+def test_detect_weakest_column_tile_left_out(mb, golden):
+    """Windows whose energy sits in two of the three tiles of spectrum columns go the long way
+    without the third tile.  (a) Two strong bins, one in each of two tiles, in every pairing of the
+    tiles: decided after the two tiles.  (b) Two tiles filled with many equal bins and a tenth of the
+    energy on one bin of the third tile, which is the true maximum: after the two tiles the rest
+    cannot be ruled out, the window is fetched again and done with all three.  (c) The same with
+    the third tile's bin weaker than the others: still the long way twice, another winner.  Several
+    streams at odd offsets; bins, classes and magnitudes are the oracle's throughout."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    rng = np.random.default_rng(43)
+    t = np.arange(7055)
+    tile_of = lambda k: min(k % 85, 85 - k % 85) // 16
+    by_tile = [[k for k in range(60, 3500) if tile_of(k) == c] for c in range(3)]
+    n_streams, n_windows, first = 3, 9, 3
+    stride = M.pad4(first + n_windows * 7055 + 11)
+    a = np.zeros((n_streams, stride), dtype=np.float32)
+    for s in range(n_streams):
+        for w in range(n_windows):
+            left_out = (s + w) % 3
+            ca, cb = [c for c in range(3) if c != left_out]
+            kind = w % 3
+            if kind == 0:
+                x = np.cos(2 * np.pi * int(rng.choice(by_tile[ca])) * t / 7055 + 0.3) \
+                    + 0.8 * np.cos(2 * np.pi * int(rng.choice(by_tile[cb])) * t / 7055 + 1.1)
+            else:
+                x = np.zeros(7055)
+                for c in (ca, cb):
+                    for k in rng.choice(by_tile[c], 30, replace=False):
+                        x += rng.uniform(0.7, 1.0) * np.cos(2 * np.pi * int(k) * t / 7055 + rng.uniform(0, 6.28))
+                # 60 bins of amplitude 0.7 .. 1 in two tiles; one bin in the third with amplitude 2.6 (an
+                # eighth of the energy, the maximum) or 0.6 (not the maximum)
+                x += (2.6 if kind == 1 else 0.6) * np.cos(2 * np.pi * int(rng.choice(by_tile[left_out])) * t / 7055 + 0.5)
+            a[s, first + w * 7055:first + (w + 1) * 7055] = 0.02 * x
+    mb.detect_stats()
+    cls, mag, kbin = mb.detect(dev(a), n_streams, stride, n_windows, first)
+    st = mb.detect_stats(paths=True)
+    assert st[0] == n_streams * n_windows
+    assert st[7] >= 20                      # most windows left their weakest tile out ...
+    assert st[5] >= 8                       # ... and those of kind (b) were done again with all three
+    for s in range(n_streams):
+        ob, om, oc = oracle_windows(a[s, first:first + n_windows * 7055], lut, 7055)
+        assert np.array_equal(kbin[s].cpu().numpy(), ob)
+        assert np.array_equal(cls[s].cpu().numpy().astype(np.uint16), oc)
+        assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
+
+
 @pytest.mark.parametrize("scheme", ["B", "A"])
 def test_detect_random_mixtures(mb, ma, golden, scheme):
     """Windows drawn at random: up to four tones of log-uniform strengths on arbitrary (not

@@ -32,6 +32,7 @@ struct wn_ctx {
     int detect_profile;
     float detect_share;    // share of the pilot's energy in one column tile that sends a window the one-tile way
     float detect_two_share;   // the weakest column tile is left out when the pilot finds at most this share in it (0: never)
+    int detect_per_cu;     // 1: one detection workgroup per CU even where two fit (diagnostic)
     int synth_per_cu;
     int synth_table_lds;   // 1: keep the quarter-wave table in LDS whatever the scheme (WN_SYNTH_TABLE=lds)
     long long synth_part;

@@ -330,6 +330,7 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
         const float v = (float)atof(e);
         if (v >= 0.0f && v < 0.34f) ctx->detect_two_share = v;
     }
+    if (const char *e = getenv("WN_DETECT_PER_CU")) ctx->detect_per_cu = atoi(e);
     if (const char *e = getenv("WN_SYNTH_PER_CU")) ctx->synth_per_cu = atoi(e);
     if (const char *e = getenv("WN_SYNTH_TABLE")) ctx->synth_table_lds = e[0] == 'l';
     if (const char *e = getenv("WN_SYNTH_PART")) ctx->synth_part = atoll(e);

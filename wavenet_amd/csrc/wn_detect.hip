@@ -1355,7 +1355,10 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     // the first one's matrix instructions
     constexpr int PER_CU = (2 * P::LDS <= 160 * 1024 && 2 * (P::TA * 16 + 160) <= 512) ? 2 : 1;
     long long blocks = (total + 3) / 4;
-    if (blocks > (long long)ctx->num_cus * PER_CU) blocks = (long long)ctx->num_cus * PER_CU;
+    // WN_DETECT_PER_CU=1 (read when the context is made) holds the short-window kernel to one workgroup
+    // per CU: the measure of what a second wave per SIMD is worth to this code
+    const int per_cu = (ctx->detect_per_cu == 1) ? 1 : PER_CU;
+    if (blocks > (long long)ctx->num_cus * per_cu) blocks = (long long)ctx->num_cus * per_cu;
     // Which windows the float32 spectrum may decide.  u = 2^-24.  A folded sample (sum or
     // difference of four samples, two roundings) is within 2u of exact relative to the sum q of
     // the four magnitudes; a stage-1 output adds a rounded twiddle (u) and at most 4*KS1 <= 44
