@@ -125,14 +125,16 @@ int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
  * tile of 16 outputs, spectrum column) products of the second stage (((n1+1)/2 + 15)/16 tiles times
  * (n2+1)/2 columns k mod n2, folded, per window at most),
  * out[4] (row tile of 16, real or imaginary part, column) products of the first stage
- * (((n1+1)/2 + 15)/16*2 tiles times 2 times (n2+1)/2 columns per window at most), out[5] windows that were started on one column tile and
- * had to be done again on all of them (their work is counted twice in out[3], out[4]), out[6] windows
- * whose first stage was computed for every column tile (those of out[5] included); out[7] is
- * reserved and zero.  The rest
- * was left out because the energy outside the outputs already seen could not reach the decision
- * threshold.  One set of counters per context, summed over every thread and stream that detects
- * with it. */
-int wn_detect_stats(wn_ctx *ctx, int64_t out[8], void *stream);
+ * (((n1+1)/2 + 15)/16*2 tiles times 2 times (n2+1)/2 columns per window at most), out[5] windows
+ * that were started on part of the columns (one column tile, sixteen chosen columns, or all tiles
+ * but the weakest) and had to be done again on more (their work is counted again in out[3],
+ * out[4]), out[6] passes "the long way" (first stage of every column tile, or of all but the
+ * weakest; those of out[5] included), out[7] of them those that left the weakest column tile out,
+ * out[8] windows that took one tile of sixteen columns chosen for them; out[9] is reserved and
+ * zero.  The rest was left out because the energy outside the outputs already seen could not reach
+ * the decision threshold.  One set of counters per context, summed over every thread and stream
+ * that detects with it. */
+int wn_detect_stats(wn_ctx *ctx, int64_t out[10], void *stream);
 
 /* ---- K4: checksum and frames ------------------------------------------------------- */
 /* calcular_checksum (B:178-187; A:89) over n messages: d_out[i] = zlib CRC-32 of

@@ -602,13 +602,84 @@ def test_detect_weakest_column_tile_left_out(mb, golden):
     cls, mag, kbin = mb.detect(dev(a), n_streams, stride, n_windows, first)
     st = mb.detect_stats(paths=True)
     assert st[0] == n_streams * n_windows
-    assert st[7] >= 20                      # most windows left their weakest tile out ...
+    assert st[7] >= 16                      # the windows of many bins left their weakest tile out ...
     assert st[5] >= 8                       # ... and those of kind (b) were done again with all three
+    assert st[8] >= 8                       # the windows of two bins took one tile of chosen columns instead
     for s in range(n_streams):
         ob, om, oc = oracle_windows(a[s, first:first + n_windows * 7055], lut, 7055)
         assert np.array_equal(kbin[s].cpu().numpy(), ob)
         assert np.array_equal(cls[s].cpu().numpy().astype(np.uint16), oc)
         assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
+
+
+def test_detect_sixteen_chosen_columns(monkeypatch, mb, golden):
+    """Windows whose energy sits in a few spectrum columns of different column tiles get one tile made
+    of the sixteen strongest columns, with twiddles and bins worked out per window.  (a) The separator
+    ending and a data tone beginning anywhere in the window (what a receiver mostly sees).  (b) A bin
+    of column 0 (a multiple of 85: its mirrored outputs repeat the plain ones), or of row 0 (a
+    multiple of 83: likewise), with a stronger bin in another tile.  (c) The one bin the reference never looks at (3527) louder than
+    everything, with bins in the two other tiles: the loudest of those is the answer.  (d) A constant
+    offset with two tones.  (e) Forty bins all over: too many columns, the long way.  Bins, classes
+    and magnitudes are the oracle's; the same windows with the choice switched off give the same."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    rng = np.random.default_rng(71)
+    t = np.arange(7055)
+    col = lambda k: min(k % 85, 85 - k % 85)
+    tile_of = lambda k: col(k) // 16
+    by_tile = [[k for k in range(60, 3500) if tile_of(k) == c] for c in range(3)]
+    n_streams, n_windows, first = 3, 20, 2
+    stride = M.pad4(first + n_windows * 7055 + 7)
+    a = np.zeros((n_streams, stride), dtype=np.float32)
+    kinds = []
+    for s in range(n_streams):
+        for w in range(n_windows):
+            kind = (s + w) % 5
+            kinds.append(kind)
+            if kind == 0:
+                cut = int(rng.integers(2200, 4900))
+                x = 0.5 * np.sin(2 * np.pi * 200 * t / 44100)
+                x[cut:] = 0.5 * np.sin(2 * np.pi * (350 + 70 * int(rng.integers(0, 256))) * t[cut:] / 44100)
+            elif kind == 1:
+                if w % 2:
+                    special = 85 * int(rng.integers(2, 40))
+                    other = int(rng.choice(by_tile[1 + (w // 2) % 2]))
+                    ratio = 1.5
+                else:
+                    special = 83 * int(rng.choice([m for m in range(2, 42) if tile_of(83 * m) != 0]))
+                    other = int(rng.choice(by_tile[0]))
+                    ratio = 1.2
+                x = 0.3 * np.cos(2 * np.pi * special * t / 7055 + 0.2) + 0.3 * ratio * np.cos(2 * np.pi * other * t / 7055 + 1.0)
+            elif kind == 2:
+                x = 0.4 * np.cos(2 * np.pi * 3527 * t / 7055 + 0.1) \
+                    + 0.36 * np.cos(2 * np.pi * int(rng.choice(by_tile[0])) * t / 7055 + 0.7) \
+                    + 0.25 * np.cos(2 * np.pi * int(rng.choice(by_tile[1])) * t / 7055 + 2.0)
+            elif kind == 3:
+                x = 0.12 + 0.3 * np.cos(2 * np.pi * int(rng.choice(by_tile[1])) * t / 7055) \
+                    + 0.28 * np.cos(2 * np.pi * int(rng.choice(by_tile[2])) * t / 7055 + 0.4)
+            else:
+                x = np.zeros(7055)
+                for k in rng.choice(np.arange(60, 3500), 40, replace=False):
+                    x += 0.07 * rng.uniform(0.7, 1.0) * np.cos(2 * np.pi * int(k) * t / 7055 + rng.uniform(0, 6.28))
+            a[s, first + w * 7055:first + (w + 1) * 7055] = x
+    few = sum(1 for k in kinds if k != 4)
+    monkeypatch.setenv("WN_DETECT_PICK", "0")
+    off = M.Modem(M.esquema_b())
+    for m, on in ((mb, True), (off, False)):
+        m.detect_stats()
+        cls, mag, kbin = m.detect(dev(a), n_streams, stride, n_windows, first)
+        st = m.detect_stats(paths=True)
+        assert st[0] == n_streams * n_windows
+        if on:
+            # most windows of kinds (a) to (d) (in some both tones share a column tile, and the pilot, which
+            # sees a part of the rows, can find more than 70 % in one tile), none of kind (e)
+            assert st[8] >= few // 2 and st[8] <= few
+        else:
+            assert st[8] == 0 and st[6] >= few // 2
+        for s in range(n_streams):
+            ob, om, oc = oracle_windows(a[s, first:first + n_windows * 7055], lut, 7055)
+            assert np.array_equal(kbin[s].cpu().numpy(), ob)
+            assert np.array_equal(cls[s].cpu().numpy().astype(np.uint16), oc)
+            assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
 
 
 @pytest.mark.parametrize("scheme", ["B", "A"])

@@ -20,7 +20,7 @@ struct wn_ctx {
     float2 *d_tw1;        // n1 entries (cos, sin)(2*pi*m/n1)
     float2 *d_tw2;        // n2 entries (cos, -sin)(2*pi*m/n2)
     double tie_band;
-    unsigned long long *d_stats;  // 8 counters (5 used)
+    unsigned long long *d_stats;  // 16 counters (9 used)
     // sync: ping bins [lo, hi]
     int32_t ping_lo, ping_hi;
     // checksum: slicing-by-4 tables [4][256]
@@ -32,6 +32,7 @@ struct wn_ctx {
     int detect_profile;
     float detect_share;    // share of the pilot's energy in one column tile that sends a window the one-tile way
     float detect_two_share;   // the weakest column tile is left out when the pilot finds at most this share in it (0: never)
+    float detect_pick_share;  // class width of the choice of sixteen spectrum columns, as a share of the pilot's energy (0: never)
     int detect_per_cu;     // 1: one detection workgroup per CU even where two fit (diagnostic)
     int synth_per_cu;
     int synth_table_lds;   // 1: keep the quarter-wave table in LDS whatever the scheme (WN_SYNTH_TABLE=lds)

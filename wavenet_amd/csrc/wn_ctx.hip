@@ -309,8 +309,8 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
         INIT_TRY(upload(&ctx->d_crc_combine_tab, t.data(), t.size()));
     }
     if (const char *e = getenv("WN_CRC_COMBINE")) ctx->crc_combine = atoi(e) != 0;
-    INIT_HIP(hipMalloc((void **)&ctx->d_stats, 8 * sizeof(unsigned long long)));
-    INIT_HIP(hipMemset(ctx->d_stats, 0, 8 * sizeof(unsigned long long)));
+    INIT_HIP(hipMalloc((void **)&ctx->d_stats, 16 * sizeof(unsigned long long)));
+    INIT_HIP(hipMemset(ctx->d_stats, 0, 16 * sizeof(unsigned long long)));
     if ((size_t)(ctx->n + n1 + n2) * sizeof(double2) > 150 * 1024) {
         wn_set_error("window length %d too large for the float64 phase table", ctx->n);
         wn_ctx_destroy(ctx);
@@ -329,6 +329,11 @@ extern "C" int wn_scheme_init(const wn_scheme *s, wn_ctx **out) {
     if (const char *e = getenv("WN_DETECT_TWO")) {
         const float v = (float)atof(e);
         if (v >= 0.0f && v < 0.34f) ctx->detect_two_share = v;
+    }
+    ctx->detect_pick_share = 1.0f / 128.0f;
+    if (const char *e = getenv("WN_DETECT_PICK")) {
+        const float v = (float)atof(e);
+        if (v >= 0.0f && v <= 0.25f) ctx->detect_pick_share = v;
     }
     if (const char *e = getenv("WN_DETECT_PER_CU")) ctx->detect_per_cu = atoi(e);
     if (const char *e = getenv("WN_SYNTH_PER_CU")) ctx->synth_per_cu = atoi(e);
@@ -365,13 +370,13 @@ extern "C" int wn_detect_set_tie_band(wn_ctx *ctx, double rel) {
     return WN_OK;
 }
 
-extern "C" int wn_detect_stats(wn_ctx *ctx, int64_t out[8], void *stream) {
+extern "C" int wn_detect_stats(wn_ctx *ctx, int64_t out[10], void *stream) {
     WN_REQUIRE(ctx && out, "ctx/out");
-    unsigned long long h[8];
+    unsigned long long h[10];
     hipStream_t st = (hipStream_t)stream;
     WN_HIP_TRY(hipMemcpyAsync(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost, st));
     WN_HIP_TRY(hipMemsetAsync(ctx->d_stats, 0, sizeof(h), st));
     WN_HIP_TRY(hipStreamSynchronize(st));
-    for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
+    for (int i = 0; i < 10; ++i) out[i] = (int64_t)h[i];
     return WN_OK;
 }

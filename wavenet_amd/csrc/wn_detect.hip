@@ -127,10 +127,14 @@ struct Plan {
     // pilot: bf16 matrix instructions of K = 32, k-steps 8m .. 8m+7 of lane group g in slots 8g .. 8g+7
     static constexpr int NM = (KS1 + 7) / 8;
     // LDS map (bytes): class table, the pilot's B operands (16 bytes per lane for each of
-    // NM x C2T x {cos, -sin}), then one window buffer per wave
+    // NM x C2T x {cos, -sin}), two small tables, then one window buffer per wave
     static constexpr int OFF_LUT = 0;
     static constexpr int OFF_PTW = OFF_LUT + (((N / 2) * 2 + 15) & ~15);
-    static constexpr int OFF_XW = OFF_PTW + NM * C2T * 2 * 1024;
+    // for windows that take sixteen chosen spectrum columns: the stage-1 twiddle table and the bin
+    // term (k2*E2) mod N of every kept column
+    static constexpr int OFF_TW2 = OFF_PTW + NM * C2T * 2 * 1024;
+    static constexpr int OFF_CB = OFF_TW2 + ((N2 * 8 + 15) & ~15);
+    static constexpr int OFF_XW = OFF_CB + ((K2 * 4 + 15) & ~15);
     static constexpr size_t LDS = (size_t)OFF_XW + (size_t)4 * XW * 4;
     // idempotents of the index map: bin of Z[j][k2] is (j*E1 + k2*E2) mod N
     static constexpr int idem(int own, int other) {
@@ -177,6 +181,13 @@ __device__ __forceinline__ void mfma1_acc(floatx4 &y, float a, float b_acc) {
 }
 __device__ __forceinline__ void mfma1_new(floatx4 &y, float a, float b_acc) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(y) : "v"(a), "a"(b_acc));
+}
+// the same with the B operand in an ordinary register
+__device__ __forceinline__ void mfma1v_acc(floatx4 &y, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(y) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma1v_new(floatx4 &y, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&a"(y) : "v"(a), "v"(b));
 }
 // declares an accumulation register written (no instruction): the statements below update it in place
 __device__ __forceinline__ void acc_declare(floatx4 &y) { asm volatile("" : "=a"(y)); }
@@ -239,6 +250,12 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+// |a - b| for a per-lane a and a wave-uniform b
+__device__ __forceinline__ unsigned absdiff_u32(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
 // a value that lives in an accumulation register from here on
 __device__ __forceinline__ void acc_const(float &dst, float v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); }
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                                                         const float2 *__restrict__ g_tw2,
                                                         const uint16_t *__restrict__ lut, float keep,
                                                         float err_lin, float err_sq, float one_share, float two_share,
-                                                        uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
+                                                        float pick_share, uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
                                                         int32_t *__restrict__ out_bin,
                                                         unsigned long long *__restrict__ stats) {
     typedef Plan<N1, N2> P;
@@ -331,6 +348,9 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         uintx4 w4 = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
         *(uintx4 *)(smem + P::OFF_PTW + idx * 1024 + ln * 16) = w4;
     }
+
+    for (int i = threadIdx.x; i < N2; i += 256) ((float2 *)(smem + P::OFF_TW2))[i] = g_tw2[i];
+    for (int i = threadIdx.x; i < P::K2; i += 256) ((int *)(smem + P::OFF_CB))[i] = (int)(((long long)i * P::E2) % N);
 
     const int li = lane & 15;  // A row / B column / D column
     const int lg = lane >> 4;  // A,B k index / D row group
@@ -528,30 +548,42 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     };
 
     // PROF build only: shader clocks spent per phase of the window loop, summed over this wave's windows
-    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = 0;
+    // (the sums live in LDS behind the window buffers, 32 per wave: in registers they cost the build the
+    // registers its kernel needs)
+    volatile unsigned long long *prof = (volatile unsigned long long *)(smem + P::LDS) + 32 * wave;
+    unsigned long long prof_t = 0;
+    if constexpr (PROF) {
+        for (int i = 0; i < 32; ++i) prof[i] = 0ull;
+    }
     const unsigned long long prof_r0 = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const unsigned long long prof_c0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
     auto lap = [&](auto I) {
         if constexpr (PROF) {
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long now = __builtin_amdgcn_s_memtime();
-            prof[decltype(I)::value] += now - prof_t;
+            prof[decltype(I)::value] = prof[decltype(I)::value] + (now - prof_t);
             prof_t = now;
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
+    // PROF build only: windows and clocks by the way a window went (0 one column tile; 1 the long way without
+    // the weakest tile; 2 the long way with every tile; 3 one tile, then the long way; 4 the long way twice;
+    // 5 sixteen chosen columns; 6 those, then the long way)
+    // (prof[12 + way]: windows, prof[19 + way]: clocks)
+    unsigned long long path_t0 = 0;
     unsigned long long s1_units = 0;    // (row tile, real or imaginary part, column) products of stage 1 this wave computed (statistics)
     unsigned long long redone = 0;      // windows done a second time, the whole way
     unsigned long long whole_n = 0;     // passes the long way (windows done twice included)
     unsigned long long two_n = 0;       // of them: with one column tile left out
+    unsigned long long pick_n = 0;      // windows that took sixteen chosen columns
     int next_off = 0;
     if (w < total) {
         next_off = fetch(f_s, f_w);
         advance();
     }
     while (w < total) {
-        if constexpr (PROF) prof_t = __builtin_amdgcn_s_memtime();
+        if constexpr (PROF) path_t0 = prof_t = __builtin_amdgcn_s_memtime();
         const int xb = 4 * (xw_f + next_off);   // byte address of sample 0 of this window
         int ad_p[T1], ad_m[T1];
 #pragma unroll
@@ -574,16 +606,20 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         floatx2 e4[TA];            // running sums of the squared A operands, per row-tile pair
         floatx2 sx[TA];            // running sums of the A operands (.x: the sum of the four samples)
         floatx2 xs0[KS1], xd0[KS1];   // A operands of row-tile pair 0 for every k-step, folded by the pilot
-        // Stage 1 comes in two cuts.  WHOLE: every row tile of every column tile.  ONE<c>: every row
+        // stage-1 twiddles of the sixteen chosen columns: read from the table k-step by k-step (byte offset
+        // pk_i8 of this lane's entry for the next k-step, climbing by pk_k8 modulo the table)
+        unsigned pk_i8 = 0u, pk_k8 = 0u;
+        // Stage 1 comes in three cuts.  WHOLE: every row tile of every column tile.  ONE<c>: every row
         // tile of column tile c only, for windows whose energy the pilot (below) finds in one
-        // column tile.
+        // column tile.  PICK: every row tile of one tile made of sixteen columns chosen for this window
+        // (twiddles in dtc / dts, results where column tile 0 has its own).
         // The sample reads of k-step ks+2 are issued one after each matrix instruction of k-step
         // ks (an LDS instruction issues while the matrix pipe works on the one before it; the
         // vector instructions of the folds do not), into the register set that the fold of
         // k-step ks has already consumed.
         // (Doing the k-steps in pairs, for half as many changes between matrix and vector work, was
         // slower: 24 LDS reads in one go exceed the 15 the wave may have outstanding.)
-        constexpr int WHOLE = 1, ONE = 2;
+        constexpr int WHOLE = 1, ONE = 2, PICK = 3;
         auto stage1 = [&](auto CUT_, auto CSEL_, unsigned need) {   // need (WHOLE only): the column tiles to compute, wave-uniform
             constexpr int CUT = decltype(CUT_)::value, CSEL = decltype(CSEL_)::value;
             // row-tile pairs gathered here: all of them, or all but pair 0 when the pilot kept its operands
@@ -623,6 +659,18 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     asm volatile("" : "+v"(e4[t]), "+v"(sx[t]));
                 });
             };
+            floatx2 dtw[2];   // PICK: (cos, -sin) of this lane's column for k-steps ks (even: [0], odd: [1])
+            auto tw_rd = [&](auto KS) {
+                constexpr int ks = decltype(KS)::value;
+                if constexpr (CUT == PICK && ks < KS1) {
+                    const float2 t = *(const float2 *)(smem + P::OFF_TW2 + pk_i8);
+                    pk_i8 += pk_k8;
+                    pk_i8 = min(pk_i8, pk_i8 - 8u * N2);
+                    dtw[ks & 1][0] = t.x;
+                    dtw[ks & 1][1] = t.y;
+                }
+            };
+            tw_rd(ic<0>{});
             if constexpr (CUT == WHOLE && C2T > 2) {
                 static_for<C2T>([&](auto C) {
                     static_for<T1>([&](auto T) {
@@ -642,20 +690,42 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 static_for<C2T>([&](auto C) {
                     constexpr int c = decltype(C)::value;
                     auto tile = [&]() {
+                        float pc = 0.f, ps = 0.f;   // PICK: this k-step's twiddles, padding and the halved first column applied
+                        if constexpr (CUT == PICK) {
+                            pc = dtw[ks & 1][0];
+                            ps = dtw[ks & 1][1];
+                            if constexpr (ks == 0) pc *= w_first;
+                            if constexpr (ks == KS1 - 1) {
+                                pc *= w_last;
+                                ps *= w_last;
+                            }
+                            asm volatile("s_nop 1" ::"v"(pc), "v"(ps));   // just written, read by the next MFMA
+                        }
                         static_for<T1>([&](auto T) {
                             constexpr int t = decltype(T)::value;
                             // row-tile pair 0 takes the operands the pilot folded and kept
                             const float as = (WN_DETECT_KEEP0 && t % TA == 0) ? xs0[ks][t / TA] : xs[t % TA][t / TA];
                             const float ad = (WN_DETECT_KEEP0 && t % TA == 0) ? xd0[ks][t / TA] : xd[t % TA][t / TA];
-                            if constexpr (ks == 0) mfma1_new(Yr[c][t], as, t2c[ks][c]);
-                            else mfma1_acc(Yr[c][t], as, t2c[ks][c]);
+                            if constexpr (CUT == PICK) {
+                                if constexpr (ks == 0) mfma1v_new(Yr[c][t], as, pc);
+                                else mfma1v_acc(Yr[c][t], as, pc);
+                                if constexpr (t == 0) tw_rd(ic<ks + 1>{});   // the next k-step's pair, while this one's matrix instructions run
+                            } else {
+                                if constexpr (ks == 0) mfma1_new(Yr[c][t], as, t2c[ks][c]);
+                                else mfma1_acc(Yr[c][t], as, t2c[ks][c]);
+                            }
                             // the sample reads of k-step ks+2 ride on the first matrix instructions of a
                             // column tile; every tile that runs issues them (the same values again:
                             // which tiles run is not known when the code is laid out)
                             rd1(ic<ks + 2>{}, ic<2 * t>{});
                             __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (ks == 0) mfma1_new(Yi[c][t], ad, t2s[ks][c]);
-                            else mfma1_acc(Yi[c][t], ad, t2s[ks][c]);
+                            if constexpr (CUT == PICK) {
+                                if constexpr (ks == 0) mfma1v_new(Yi[c][t], ad, ps);
+                                else mfma1v_acc(Yi[c][t], ad, ps);
+                            } else {
+                                if constexpr (ks == 0) mfma1_new(Yi[c][t], ad, t2s[ks][c]);
+                                else mfma1_acc(Yi[c][t], ad, t2s[ks][c]);
+                            }
                             rd1(ic<ks + 2>{}, ic<2 * t + 1>{});
                             __builtin_amdgcn_sched_barrier(0);
                         });
@@ -858,13 +928,18 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // the rest cannot matter.  `more` says whether other column tiles would follow (after the
         // very last row tile of the window there is nothing left to rule out).  The last column
         // tile starts with the last row tile: that is where the separator, ping and end tones are.
-        auto col_tile = [&](auto C, bool more, auto DMA) -> bool {
+        // With PICKED the tile is the one of sixteen chosen columns (results where column tile 0 has
+        // its own): lane column `pk_col`, bins computed from the per-window terms pk_u / pk_v below.
+        unsigned pk_u = 0u, pk_v = 0u;     // ((4*lg*E1 + k2*E2) mod N, (k2*E2 - 4*lg*E1) mod N) of this lane's column k2
+        bool pk_col0 = false, pk_x = false;   // this lane's column is k2 = 0; this lane holds the bin that is never looked at
+        auto col_tile = [&](auto C, bool more, auto DMA, auto PICKED) -> bool {
             constexpr int c = decltype(C)::value;
             constexpr bool dma = decltype(DMA)::value != 0;   // the first cell issues the next window's transfer
+            constexpr bool picked = decltype(PICKED)::value != 0;
             bool done = false;
             static_for<TA>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                constexpr int tt = c == C2T - 1 ? (i == 0 ? TA - 1 : i - 1) : i;
+                constexpr int tt = (picked || c == C2T - 1) ? (i == 0 ? TA - 1 : i - 1) : i;
                 if (!done) {
                     floatx4 acc[4];   // the sums A, B, C, E
                     static_for<KS2>([&](auto S) {
@@ -912,15 +987,34 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                         static_for<2>([&](auto EL) {
                             constexpr int r = 2 * hf + decltype(EL)::value;
                             float mp = mp2[decltype(EL)::value], mm = mm2[decltype(EL)::value];
-                            // (the empty statement keeps the two halves from being taken apart once and for
-                            // all ahead of the window loop, which would cost the registers the packing saves)
-                            asm volatile("" : "+v"(tag[tt][r][c]));
-                            const unsigned tp = tag[tt][r][c], tm = tp >> 16;   // only the low 12 bits (and bit 15) of each are used
-                            // outputs that must not compete although their value is not zero: known positions
-                            constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
-                            if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
-                            if constexpr (c == 0 || (tt == 0 && r == 0) || (xhere && P::XMINUS))
-                                mm = __builtin_unpredictable(tm & EP_UNUSED) ? 0.f : mm;
+                            unsigned tp, tm;   // only the low 12 bits (and bit 15) of each are used
+                            if constexpr (picked) {
+                                // bin of Z[j][k2] = (j*E1 + k2*E2) mod N folded to [0, N/2], j = k1 (plus side) or
+                                // n1 - k1 (minus side: -k1*E1 mod N), k1 = 16*tt + 4*lg + r: the lane's part of the
+                                // sum comes per window, the rest is a constant of the code.  x in [0, 2N] folds to
+                                // its distance from the nearest of 0, N, 2N.
+                                constexpr unsigned CT = (unsigned)(((long long)(16 * tt + r) * P::E1) % N);
+                                const unsigned xp = pk_u + CT, xm = pk_v + ((unsigned)N - CT);
+                                tp = min(min(xp, absdiff_u32(xp, (unsigned)N)), 2u * N - xp);
+                                tm = min(min(xm, absdiff_u32(xm, (unsigned)N)), 2u * N - xm);
+                                constexpr bool xrow = tt == P::XK1 / 16 && r == P::XK1 % 4;
+                                if constexpr (xrow && !P::XMINUS) mp = pk_x ? 0.f : mp;
+                                if constexpr (xrow && P::XMINUS) mm = pk_x ? 0.f : mm;
+                                // the minus side repeats the plus side where k2 = 0 or k1 = 0
+                                if constexpr (tt == 0 && r == 0) mm = (pk_col0 | (lg == 0)) ? 0.f : mm;
+                                else mm = pk_col0 ? 0.f : mm;
+                            } else {
+                                // (the empty statement keeps the two halves from being taken apart once and for
+                                // all ahead of the window loop, which would cost the registers the packing saves)
+                                asm volatile("" : "+v"(tag[tt][r][c]));
+                                tp = tag[tt][r][c];
+                                tm = tp >> 16;
+                                // outputs that must not compete although their value is not zero: known positions
+                                constexpr bool xhere = tt == P::XK1 / 16 && r == P::XK1 % 4 && c == P::XK2 / 16;
+                                if constexpr (xhere && !P::XMINUS) mp = __builtin_unpredictable(tp & EP_UNUSED) ? 0.f : mp;
+                                if constexpr (c == 0 || (tt == 0 && r == 0) || (xhere && P::XMINUS))
+                                    mm = __builtin_unpredictable(tm & EP_UNUSED) ? 0.f : mm;
+                            }
                             best.mx = max(best.mx, max(__float_as_uint(mp), __float_as_uint(mm)));
                             top3_insert(best, (__float_as_uint(mp) & ~KEY_BIN) | (tp & KEY_BIN));
                             top3_insert(best, (__float_as_uint(mm) & ~KEY_BIN) | (tm & KEY_BIN));
@@ -929,10 +1023,11 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     // each bin once: where k2 = 0 (column tile 0, li = 0) every minus-side output repeats
                     // its plus side, and so does the one of row k1 = 0 (row tile 0, register 0, lane group 0)
                     float em = es_m.x + es_m.y;
-                    if constexpr (c == 0) em = li == 0 ? 0.f : em - (lg == 0 ? dup_row0 : 0.f);
+                    if constexpr (picked) em = pk_col0 ? 0.f : em - (lg == 0 ? dup_row0 : 0.f);
+                    else if constexpr (c == 0) em = li == 0 ? 0.f : em - (lg == 0 ? dup_row0 : 0.f);
                     else em -= lg == 0 ? dup_row0 : 0.f;
                     eproc += (es_p.x + es_p.y) + em;
-                    cells_done += NCOL[c];
+                    cells_done += picked ? 16 : NCOL[c];
                     if (i + 1 < TA || more) {
                         if (rest_cannot_matter(mxu)) {
                             have_max = true;
@@ -988,6 +1083,65 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 if (__uint_as_float(low) <= two_share * tot && tot <= 1e30f) need = ALL & ~(1u << c_min);
             }
         }
+        // Sixteen chosen columns.  A window that is not a one-tile window mostly holds two tones
+        // (one ending, one beginning) whose columns lie in different tiles; nearly all of its energy
+        // still sits in a dozen columns.  The pilot's energies per column (summed over the four lane
+        // groups) put every column in one of four classes (above 4, 1, 1/4 times `pick_share` of the
+        // total, or below); columns are taken class by class, in column order inside a class, until
+        // sixteen are chosen.  If the first two classes fit in sixteen, stage 1 computes that one tile
+        // with twiddles fetched for it, and stage 2 follows with the bins worked out per window.  The
+        // energy check decides as everywhere else whether that was enough.
+        bool picked = false;
+        if constexpr (C2T > 2) {
+            float tot = 0.f;
+#pragma unroll
+            for (int c = 0; c < C2T; ++c) tot += __uint_as_float(eo[c]);
+            if (!one_tile && pick_share > 0.f && tot <= 1e30f) {
+                float ce[C2T];
+#pragma unroll
+                for (int c = 0; c < C2T; ++c) {
+                    const unsigned a = __float_as_uint(ec[c]);
+                    const auto h = __builtin_amdgcn_permlane16_swap(a, a, false, false);      // rows (0, 0, 2, 2) and (1, 1, 3, 3)
+                    const float s2 = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+                    const auto f = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+                    ce[c] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+                }
+                // lane 16c + li speaks for column k2 = 16c + li.  (What follows is computed from a copy of the
+                // lane number the compiler cannot see through: left to itself it keeps a dozen per-lane
+                // constants of this rarely used block in registers for the whole launch.)
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int lgq = ln >> 4, liq = ln & 15;
+                const float mine = lgq == 0 ? ce[0] : (lgq == 1 ? ce[1] : ce[2]);
+                const bool valid = ln <= H2;
+                const float th = pick_share * tot;
+                const bool p1 = valid & (mine > 4.f * th), p2 = valid & (mine > th), p3 = valid & (mine > 0.25f * th);
+                const unsigned long long m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3), mv = __ballot(valid);
+                const int n1c = __popcll(m1), n2c = __popcll(m2), n3c = __popcll(m3);
+                if (n2c <= 16) {
+                    auto below = [&](unsigned long long m) {
+                        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    };
+                    int slot = p1 ? below(m1)
+                                  : (p2 ? n1c + below(m2 & ~m1) : (p3 ? n2c + below(m3 & ~m2) : n3c + below(mv & ~m3)));
+                    slot = valid ? slot : ln;   // a permutation of the lanes: columns in order of choice, then the lanes that hold none
+                    const int by_slot = __builtin_amdgcn_ds_permute(4 * slot, ln);   // lane s: the column of slot s
+                    const int k2 = __builtin_amdgcn_ds_bpermute(4 * liq, by_slot);
+                    const int kE = ((const int *)(smem + P::OFF_CB))[k2];
+                    constexpr int R1 = (int)((4ll * P::E1) % N), R2 = (int)((8ll * P::E1) % N), R3 = (int)((12ll * P::E1) % N);
+                    const int rl = lgq == 0 ? 0 : (lgq == 1 ? R1 : (lgq == 2 ? R2 : R3));
+                    pk_u = (unsigned)(kE + rl >= N ? kE + rl - N : kE + rl);
+                    pk_v = (unsigned)(kE - rl < 0 ? kE - rl + N : kE - rl);
+                    pk_col0 = k2 == 0;
+                    pk_x = k2 == P::XK2 && lgq == (P::XK1 % 16) / 4;
+                    // twiddles (cos, -sin)(2*pi*b'*k2/n2) of b' = ks + KS1*lg: the table index climbs by k2 per k-step
+                    static_assert(KS1 - 2 + KS1 * 3 <= H2, "only the last k-step holds padding");
+                    pk_i8 = 8u * (unsigned)((KS1 * lgq * k2) % N2);
+                    pk_k8 = 8u * (unsigned)k2;
+                    picked = true;
+                }
+            }
+        }
         auto refetch = [&]() {
             // The window's buffer is by now being overwritten by the next window: wait for that
             // DMA, fetch this window again (the long way then fetches the next window again).
@@ -996,21 +1150,22 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ++redone;
         };
+        int path = one_tile ? 0 : (picked ? 5 : (need != ALL ? 1 : 2));   // PROF build only
         if (one_tile) {
             // the pilot found the energy in one column tile: stage 1 and stage 2 of that tile only
             bool done = false;
             if (c_first == 0) {
                 stage1(ic<ONE>{}, ic<0>{}, 0u);
                 after_stage1(ic<1>{});
-                done = col_tile(ic<0>{}, true, ic<1>{});
+                done = col_tile(ic<0>{}, true, ic<1>{}, ic<0>{});
             } else if (c_first == 1) {
                 stage1(ic<ONE>{}, ic<1>{}, 0u);
                 after_stage1(ic<1>{});
-                done = col_tile(ic<1>{}, true, ic<1>{});
+                done = col_tile(ic<1>{}, true, ic<1>{}, ic<0>{});
             } else if constexpr (C2T > 2) {
                 stage1(ic<ONE>{}, ic<2>{}, 0u);
                 after_stage1(ic<1>{});
-                done = col_tile(ic<2>{}, true, ic<1>{});
+                done = col_tile(ic<2>{}, true, ic<1>{}, ic<0>{});
             }
             const int ncol = c_first == 0 ? NCOL[0] : (c_first == 1 ? NCOL[1] : NCOL[2]);
             s1_units += (unsigned)(OTHER_TILES * ncol);
@@ -1019,6 +1174,20 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 // over many bins: rare): the whole way.
                 refetch();
                 whole = true;
+                path = 3;
+            }
+        }
+        if (picked) {
+            stage1(ic<PICK>{}, ic<0>{}, 0u);
+            after_stage1(ic<1>{});
+            const bool done = col_tile(ic<0>{}, true, ic<1>{}, ic<1>{});
+            s1_units += (unsigned)(OTHER_TILES * 16);
+            ++pick_n;
+            if (done) {
+                whole = false;
+            } else {
+                refetch();   // not enough: the long way
+                path = 6;
             }
         }
         while (whole) {
@@ -1051,14 +1220,15 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 // after the very last row tile of a window there is nothing left to rule out; tiles
                 // that were left out still have to be
                 const bool more = todo != 0u || need != ALL;
-                if (c == 0) done = col_tile(ic<0>{}, more, ic<0>{});
-                else if (c == 1) done = col_tile(ic<1>{}, more, ic<0>{});
-                else if constexpr (C2T > 2) done = col_tile(ic<2>{}, more, ic<0>{});
+                if (c == 0) done = col_tile(ic<0>{}, more, ic<0>{}, ic<0>{});
+                else if (c == 1) done = col_tile(ic<1>{}, more, ic<0>{}, ic<0>{});
+                else if constexpr (C2T > 2) done = col_tile(ic<2>{}, more, ic<0>{}, ic<0>{});
                 if (done) break;
             }
             if (done || need == ALL) break;
             refetch();      // the tile that was left out is needed after all
             need = ALL;
+            path = 4;
         }
         lap(ic<3>{});
         if (wn < total) advance();
@@ -1122,6 +1292,10 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             if (!full && cand == 3) pend_mag = __int_as_float((int)(best.k3 & KEY_BIN));
         }
         lap(ic<4>{});
+        if constexpr (PROF) {
+            prof[12 + path] = prof[12 + path] + 1ull;
+            prof[19 + path] = prof[19 + path] + (prof_t - path_t0);
+        }
         w = wn;
     }
     flush();
@@ -1132,6 +1306,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         if (redone) atomicAdd(&stats[5], redone);
         if (whole_n) atomicAdd(&stats[6], whole_n);
         if (two_n) atomicAdd(&stats[7], two_n);
+        if (pick_n) atomicAdd(&stats[8], pick_n);
     }
     if constexpr (PROF) {
         // out_bin[0..6]: clocks/256 per phase (DMA wait, pilot of stage 1 and the column tiles' rough
@@ -1144,6 +1319,11 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             for (int i = 8; i < 12; ++i) out_bin[i + 1] = (int)(prof[i] >> 8);   // parts of the pilot: reads, folds, matrix instructions
             out_bin[7] = (int)((__builtin_amdgcn_s_memtime() - prof_c0) >> 8);
             out_bin[8] = (int)((__builtin_amdgcn_s_memrealtime() - prof_r0) >> 8);
+            // [13..19]: windows by the way they went, [20..26]: their clocks/256
+            for (int i = 0; i < 7; ++i) {
+                out_bin[13 + i] = (int)prof[12 + i];
+                out_bin[20 + i] = (int)(prof[19 + i] >> 8);
+            }
         }
     }
 }
@@ -1386,15 +1566,15 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     // the profiling build leaves its clock counts in out_bin[0..8] and out_mag[16 .. 16 + 4*blocks):
     // launches whose result arrays are shorter than that run the ordinary build
     if (ctx->detect_profile && total >= 16 + 4 * blocks)
-        hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
+        hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS + 1024, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
-                           d_cls, d_mag, d_bin, stats);
+                           ctx->detect_pick_share, d_cls, d_mag, d_bin, stats);
     else
         hipLaunchKernelGGL((detect_kernel<N1, N2, false>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
-                           d_cls, d_mag, d_bin, stats);
+                           ctx->detect_pick_share, d_cls, d_mag, d_bin, stats);
     return wn_launch_check("detect_kernel");
 }
 
@@ -1417,7 +1597,7 @@ static int detect_attr() {
     WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Plan<N1, N2>::LDS));
     WN_HIP_TRY(hipFuncSetAttribute((const void *)detect_kernel<N1, N2, true>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Plan<N1, N2>::LDS));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Plan<N1, N2>::LDS + 1024));   // + its clock sums
     return WN_OK;
 }
 
