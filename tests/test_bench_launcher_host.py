@@ -35,12 +35,20 @@ def test_one_gpu_is_one_process():
 
 
 def test_under_torchrun_no_second_launch():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    got = _lines([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                  "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--rank-info"],
-                 _clean_env())
+    # the port is free when it is picked and may be taken by the time torchrun binds it: another port then
+    got, err = None, ""
+    for _ in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--rank-info"],
+                           cwd=ROOT, env=_clean_env(), capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            got = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+            break
+        err = r.stderr[-2000:]
+    assert got is not None, err
     assert sorted(g["rank"] for g in got) == [0, 1] and all(g["world"] == 2 for g in got)
 
 
