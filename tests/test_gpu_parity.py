@@ -612,6 +612,61 @@ def test_detect_weakest_column_tile_left_out(mb, golden):
         assert np.allclose(mag[s].cpu().numpy(), om, rtol=1e-4)
 
 
+def test_detect_separator_bin_alone(monkeypatch, mb, golden):
+    """Windows that hold little else than the separator tone are decided from that one bin and the
+    window's energy.  (a) The separator alone, at several loudnesses down to 1e-6, with and without a
+    little noise.  (b) The separator with a data tone over the last 5 to 45 % of the window: decided
+    from the one bin while the rest cannot compete, by the usual ways beyond.  (c) The separator's
+    frequency next door (bins 31 and 33 louder than 32) and a tone twice as strong in the same
+    spectrum column (bin 32 + 85): the pilot sends them to the test, the test sends them back.  (d) The
+    separator's bin and an equally loud bin elsewhere (a tie for float64).  Bins, classes and
+    magnitudes are the oracle's; with the test switched off the same windows give the same."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    rng = np.random.default_rng(83)
+    t = np.arange(7055)
+    n_streams, n_windows = 3, 24
+    firsts = (0, 1, 3)      # every alignment of a window in its buffer
+    stride = M.pad4(3 + n_windows * 7055 + 9)
+    a = np.zeros((n_streams, stride), dtype=np.float32)
+    sep = np.sin(2 * np.pi * 200 * t / 44100)
+    for s in range(n_streams):
+        for w in range(n_windows):
+            kind = w % 6
+            if kind == 0:
+                x = 0.5 * 10.0 ** -float(rng.integers(0, 7)) * sep
+            elif kind == 1:
+                x = 0.5 * sep + 0.02 * rng.standard_normal(7055)
+            elif kind == 2:
+                cut = int(7055 * (1.0 - rng.uniform(0.05, 0.45)))
+                x = 0.5 * sep.copy()
+                x[cut:] = 0.5 * np.sin(2 * np.pi * (350 + 70 * int(rng.integers(0, 256))) * t[cut:] / 44100)
+            elif kind == 3:
+                x = 0.3 * np.cos(2 * np.pi * 31 * t / 7055) + 0.3 * np.cos(2 * np.pi * 33 * t / 7055 + 1.0) \
+                    + 0.2 * np.cos(2 * np.pi * 32 * t / 7055 + 2.0)
+            elif kind == 4:
+                x = 0.2 * np.cos(2 * np.pi * 32 * t / 7055 + 0.3) + 0.4 * np.cos(2 * np.pi * (32 + 85) * t / 7055 + 1.0)
+            else:
+                x = 0.3 * np.cos(2 * np.pi * 32 * t / 7055 + 0.3) + 0.3 * np.cos(2 * np.pi * 1000 * t / 7055 + 1.0)
+            a[s, firsts[s] + w * 7055:firsts[s] + (w + 1) * 7055] = x
+    monkeypatch.setenv("WN_DETECT_SEP", "0")
+    off = M.Modem(M.esquema_b())
+    for m, on in ((mb, True), (off, False)):
+        for s in range(n_streams):
+            m.detect_stats()
+            cls, mag, kbin = m.detect(dev(a[s:s + 1]), 1, stride, n_windows, firsts[s])
+            st = m.detect_stats(paths=True)
+            assert st[0] == n_windows
+            if on:
+                assert st[9] >= 8 and st[9] <= 12      # kinds (a), (b) and part of (c)
+                assert st[5] >= 4                      # kind (d) at least came back from the test
+            else:
+                assert st[9] == 0
+            ob, om, oc = oracle_windows(a[s, firsts[s]:firsts[s] + n_windows * 7055], lut, 7055)
+            assert np.array_equal(kbin[0].cpu().numpy(), ob)
+            assert np.array_equal(cls[0].cpu().numpy().astype(np.uint16), oc)
+            assert np.allclose(mag[0].cpu().numpy(), om, rtol=1e-4)
+
+
 def test_detect_sixteen_chosen_columns(monkeypatch, mb, golden):
     """Windows whose energy sits in a few spectrum columns of different column tiles get one tile made
     of the sixteen strongest columns, with twiddles and bins worked out per window.  (a) The separator

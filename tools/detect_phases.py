@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.getcwd())
 from wavenet_amd import modem as M  # noqa: E402
 
-assert int(os.environ.get("WN_DETECT_PROFILE", "0")), "set WN_DETECT_PROFILE=1"
+assert int(os.environ.get("WN_DETECT_PROFILE", "0")), "set WN_DETECT_PROFILE=1 (every phase) or 2 (clocks per window and way only: less disturbed)"
 m = M.Modem(M.esquema_b())
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 stride = M.pad4(m.esquema.max_frame_samples(126))
@@ -41,13 +41,13 @@ for what, audio in (("noise", 0.3 * torch.randn((S, stride), device="cuda")), ("
     extra = kbin.view(-1)[9:12].tolist()
     print("  of the pilot: sample reads %.0f, folds %.0f, matrix instructions %.0f clocks/window"
           % tuple(c * 256.0 / nw for c in extra))
-    ways = kbin.view(-1)[13:27].tolist()
+    ways = kbin.view(-1)[13:29].tolist()
     for i, name in enumerate(("one column tile", "long way, weakest tile left out", "long way, every tile",
                               "one tile, then the long way", "the long way twice", "sixteen chosen columns",
-                              "chosen columns, then the long way")):
+                              "chosen columns, then the long way", "the separator's bin alone")):
         if ways[i]:
             print("  %-34s %6d windows (%.1f %%), %8.0f clocks each"
-                  % (name, ways[i], 100.0 * ways[i] / sum(ways[:7]), ways[7 + i] * 256.0 / ways[i]))
+                  % (name, ways[i], 100.0 * ways[i] / sum(ways[:8]), ways[8 + i] * 256.0 / ways[i]))
     print("  shader clock %.3f GHz" % (v[7] / v[8] * 0.1))
     t = mag.view(-1)[16:16 + 1024].double() * 1e-5   # ms
     print("  waves ran %.3f / %.3f / %.3f ms (min / mean / max): the launch waits %.2f %% for its slowest wave"

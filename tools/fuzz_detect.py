@@ -5,7 +5,9 @@ usage: python tools/fuzz_detect.py [windows_per_scheme] [seed]
 
 Windows are drawn like tests/test_gpu_parity.py::test_detect_random_mixtures (up to four tones
 of log-uniform strengths on arbitrary frequencies, DC, noise from nothing to louder than the
-tones, partial silence, any scale) plus pairs of scheme tones meeting at a random point.  A
+tones, partial silence, any scale) plus pairs of scheme tones meeting at a random point and, for a
+scheme with a separator, the separator (slightly detuned at times) giving way to another tone
+anywhere from the start of the window to its end, at any ratio of loudness.  A
 window counts as a mismatch when the kernel's bin differs from np.argmax(|fft|[:N//2]) although
 the two largest float64 magnitudes differ by more than 1e-9 relative."""
 import os
@@ -32,7 +34,17 @@ for name, esq, n in (("B", M.esquema_b(), 7055), ("A", M.esquema_a(), 2205)):
         k = min(2000, count - done)
         x = np.zeros((k, n))
         for i in range(k):
-            if rng.random() < 0.3:
+            kind = rng.random()
+            if esq.sep_freq and kind >= 0.85:
+                f = esq.sep_freq * (1.0 + (rng.uniform(-0.015, 0.015) if rng.random() < 0.3 else 0.0))
+                g = float(rng.choice(tones))
+                cut = int(n * min(1.0, rng.uniform(0.0, 1.4)))
+                x[i] = np.where(t < cut, np.sin(2 * np.pi * f * (t + rng.integers(0, 5000)) / 44100),
+                                10 ** rng.uniform(-1, 0.5) * np.sin(2 * np.pi * g * (t - cut) / 44100))
+                if rng.random() < 0.5:
+                    x[i] = x[i][::-1]
+                x[i] += 10 ** rng.uniform(-5, -0.3) * rng.standard_normal(n)
+            elif kind < 0.3:
                 f, g = float(rng.choice(tones)), float(rng.choice(tones))
                 cut = int(rng.integers(0, n + 1))
                 x[i] = np.where(t < cut, np.sin(2 * np.pi * f * (t + rng.integers(0, 5000)) / 44100),
@@ -64,8 +76,8 @@ for name, esq, n in (("B", M.esquema_b(), 7055), ("A", M.esquema_a(), 2205)):
         rel = np.abs(mag.cpu().numpy()[0][ok] - spec.max(axis=1)[ok]) / spec.max(axis=1)[ok]
         assert rel.max() <= 1e-4, rel.max()
         done += k
-    st = m.detect_stats(columns=True)
+    st = m.detect_stats(paths=True)
     print("scheme %s: %d windows, %d mismatches, %d with float64 ties left out; float64 candidates %d, float64 spectra %d, "
-          "stage-2 products per window %.1f, windows done twice %d" % (name, done, bad, unclear, st[1], st[2], st[3] / max(st[0], 1), st[5]),
-          flush=True)
+          "stage-2 products per window %.1f, windows done twice %d, on sixteen chosen columns %d, from the separator's bin alone %d"
+          % (name, done, bad, unclear, st[1], st[2], st[3] / max(st[0], 1), st[5], st[8], st[9]), flush=True)
     assert bad == 0

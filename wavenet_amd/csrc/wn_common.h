@@ -32,6 +32,8 @@ struct wn_ctx {
     int detect_profile;
     float detect_share;    // share of the pilot's energy in one column tile that sends a window the one-tile way
     float detect_two_share;   // the weakest column tile is left out when the pilot finds at most this share in it (0: never)
+    int sep_bin;              // bin nearest to the separator tone (0: the scheme has none)
+    float detect_sep_share;   // share of the pilot's energy in the separator's column from which that bin is tried alone (0: never)
     float detect_pick_share;  // class width of the choice of sixteen spectrum columns, as a share of the pilot's energy (0: never)
     int detect_per_cu;     // 1: one detection workgroup per CU even where two fit (diagnostic)
     int synth_per_cu;

@@ -134,7 +134,11 @@ struct Plan {
     // term (k2*E2) mod N of every kept column
     static constexpr int OFF_TW2 = OFF_PTW + NM * C2T * 2 * 1024;
     static constexpr int OFF_CB = OFF_TW2 + ((N2 * 8 + 15) & ~15);
-    static constexpr int OFF_XW = OFF_CB + ((K2 * 4 + 15) & ~15);
+    // for the one-bin test of separator windows: exp(2*pi*i*kc*m/N) for the 256 positions m of a chunk,
+    // then (cos, sin, -sin, cos) of exp(2*pi*i*kc*256*j/N) for every chunk j
+    static constexpr int NCH = (N + 3 + 255) / 256;
+    static constexpr int OFF_SEP = OFF_CB + ((K2 * 4 + 15) & ~15);
+    static constexpr int OFF_XW = OFF_SEP + 256 * 8 + NCH * 16;
     static constexpr size_t LDS = (size_t)OFF_XW + (size_t)4 * XW * 4;
     // idempotents of the index map: bin of Z[j][k2] is (j*E1 + k2*E2) mod N
     static constexpr int idem(int own, int other) {
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                                                         const float2 *__restrict__ g_tw2,
                                                         const uint16_t *__restrict__ lut, float keep,
                                                         float err_lin, float err_sq, float one_share, float two_share,
-                                                        float pick_share, uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
+                                                        float pick_share, int sep_bin, float sep_share, int prof_mode,
+                                                        uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
                                                         int32_t *__restrict__ out_bin,
                                                         unsigned long long *__restrict__ stats) {
     typedef Plan<N1, N2> P;
@@ -351,6 +356,15 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
 
     for (int i = threadIdx.x; i < N2; i += 256) ((float2 *)(smem + P::OFF_TW2))[i] = g_tw2[i];
     for (int i = threadIdx.x; i < P::K2; i += 256) ((int *)(smem + P::OFF_CB))[i] = (int)(((long long)i * P::E2) % N);
+    if (sep_share > 0.f) {
+        double sn, cs;
+        sincospi(2.0 * (double)(((long long)sep_bin * threadIdx.x) % N) / (double)N, &sn, &cs);
+        ((float2 *)(smem + P::OFF_SEP))[threadIdx.x] = make_float2((float)cs, (float)sn);
+        if (threadIdx.x < P::NCH) {
+            sincospi(2.0 * (double)(((long long)sep_bin * 256 * threadIdx.x) % N) / (double)N, &sn, &cs);
+            ((float4 *)(smem + P::OFF_SEP + 256 * 8))[threadIdx.x] = make_float4((float)cs, (float)sn, -(float)sn, (float)cs);
+        }
+    }
 
     const int li = lane & 15;  // A row / B column / D column
     const int lg = lane >> 4;  // A,B k index / D row group
@@ -557,27 +571,33 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     }
     const unsigned long long prof_r0 = PROF ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const unsigned long long prof_c0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+    // (prof_mode 2: only the clocks per window and way, taken at the end of a window; the laps in between
+    // cost a window about a tenth more)
     auto lap = [&](auto I) {
         if constexpr (PROF) {
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            prof[decltype(I)::value] = prof[decltype(I)::value] + (now - prof_t);
-            prof_t = now;
+            if (prof_mode == 1 || decltype(I)::value == 4) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                if (prof_mode == 1) prof[decltype(I)::value] = prof[decltype(I)::value] + (now - prof_t);
+                prof_t = now;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     // PROF build only: windows and clocks by the way a window went (0 one column tile; 1 the long way without
     // the weakest tile; 2 the long way with every tile; 3 one tile, then the long way; 4 the long way twice;
-    // 5 sixteen chosen columns; 6 those, then the long way)
-    // (prof[12 + way]: windows, prof[19 + way]: clocks)
+    // 5 sixteen chosen columns; 6 those, then the long way; 7 the separator's bin alone)
+    // (prof[12 + way]: windows, prof[20 + way]: clocks)
     unsigned long long path_t0 = 0;
     unsigned long long s1_units = 0;    // (row tile, real or imaginary part, column) products of stage 1 this wave computed (statistics)
     unsigned long long redone = 0;      // windows done a second time, the whole way
     unsigned long long whole_n = 0;     // passes the long way (windows done twice included)
     unsigned long long two_n = 0;       // of them: with one column tile left out
     unsigned long long pick_n = 0;      // windows that took sixteen chosen columns
+    unsigned long long sep_n = 0;       // windows decided from the separator's bin alone
     int next_off = 0;
+    bool sep_tried = false;   // this window has been through the separator's test and came back
     if (w < total) {
         next_off = fetch(f_s, f_w);
         advance();
@@ -812,7 +832,9 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             };
             if constexpr (WN_DETECT_KEEP0) twiddles(ic<0>{});
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (PROF) {
+                if (prof_mode == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             lap(ic<8>{});
             float hs = 0.f, hd = 0.f;
             static_for<8 * P::NM>([&](auto KS) {
@@ -907,6 +929,109 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         }
         lap(ic<1>{});
 
+        auto refetch = [&]() {
+            // The window's buffer is by now being overwritten by the next window: wait for that
+            // DMA, fetch this window again (the long way then fetches the next window again).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            (void)fetch(cur_s, cur_w);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ++redone;
+        };
+        // The separator alone.  Two windows in five hold little else than the separator tone, whose bin is
+        // known beforehand.  When the pilot finds nearly everything in that bin's column, the bin is
+        // computed by itself: per chunk of 256 samples every lane multiplies its four samples by
+        // fixed phase factors, the chunk's sum is turned by the chunk's own factor, and the window's
+        // energy is summed beside it (no matrix instructions, a tenth of the one-tile way).  If
+        // everything outside that bin holds less than the limit below which nothing can compete, the
+        // window is decided: same bound, same limit as after any part of the spectrum.  Otherwise the
+        // window goes on as if nothing had happened.
+        int path = 7;   // PROF build only
+        bool sep_done = false;
+        if constexpr (C2T > 2) {
+            float tot = 0.f;
+#pragma unroll
+            for (int c = 0; c < C2T; ++c) tot += __uint_as_float(eo[c]);
+            const int scol = min(sep_bin % N2, N2 - sep_bin % N2);   // the bin's spectrum column
+            const float in_tile = (scol >> 4) == 0 ? ec[0] : ((scol >> 4) == 1 ? ec[1] : ec[2]);
+            if (sep_share > 0.f && !sep_tried && tot <= 1e30f &&
+                lane63(wave_sum63(li == (scol & 15) ? in_tile : 0.f)) >= sep_share * tot) {
+                const floatx4 *buf = (const floatx4 *)(smf + xw_f) + lane;   // float 256*j + 4*lane + q of the buffer is sample 256*j + 4*lane + q - off
+                const floatx4 *utab = (const floatx4 *)(smem + P::OFF_SEP + 256 * 8);
+                const floatx4 p01 = ((const floatx4 *)(smem + P::OFF_SEP))[2 * lane], p23 = ((const floatx4 *)(smem + P::OFF_SEP))[2 * lane + 1];
+                const int off = next_off;
+                floatx2 acc = {0.f, 0.f}, e2 = {0.f, 0.f}, sx2 = {0.f, 0.f};
+                floatx4 xr[4], ur[4];
+                auto ld = [&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    if constexpr (j < P::NCH) {
+                        xr[j & 3] = buf[64 * j];
+                        ur[j & 3] = utab[j];
+                    }
+                };
+                ld(ic<0>{});
+                ld(ic<1>{});
+                ld(ic<2>{});
+                static_for<P::NCH>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    ld(ic<j + 3>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    floatx4 x = xr[j & 3];
+                    const floatx4 u = ur[j & 3];
+                    if constexpr (j == 0 || 256 * (j + 1) > N) {   // floats before the window's first sample, after its last
+                        const int i0 = 256 * j + 4 * lane - off;
+                        x.x = (unsigned)(i0 + 0) < (unsigned)N ? x.x : 0.f;
+                        x.y = (unsigned)(i0 + 1) < (unsigned)N ? x.y : 0.f;
+                        x.z = (unsigned)(i0 + 2) < (unsigned)N ? x.z : 0.f;
+                        x.w = (unsigned)(i0 + 3) < (unsigned)N ? x.w : 0.f;
+                    }
+                    floatx2 sj = floatx2{x.x, x.x} * p01.lo;
+                    sj += floatx2{x.y, x.y} * p01.hi;
+                    sj += floatx2{x.z, x.z} * p23.lo;
+                    sj += floatx2{x.w, x.w} * p23.hi;
+                    acc += floatx2{sj.x, sj.x} * u.lo;
+                    acc += floatx2{sj.y, sj.y} * u.hi;
+                    e2 += x.lo * x.lo;
+                    e2 += x.hi * x.hi;
+                    sx2 += x.lo;
+                    sx2 += x.hi;
+                    // keeps the sums here (left to itself the compiler holds every chunk's samples in registers
+                    // and adds them up after the loop)
+                    asm volatile("" : "+v"(acc), "+v"(e2), "+v"(sx2));
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                // The next window's transfer starts as soon as the last chunk has been read (its values are in
+                // these sums), before the sums are collected: nothing else would run while it is under way.  A
+                // window that is not decided here after all is fetched again.
+                asm volatile("" ::"v"(acc), "v"(e2));
+                next_window_dma();
+                pend = false;
+                __builtin_amdgcn_sched_barrier(0);
+                const float zr = lane63(wave_sum63(acc.x)), zi = lane63(wave_sum63(acc.y));
+                const float s2 = lane63(wave_sum63(e2.x + e2.y)), s1 = lane63(wave_sum63(sx2.x + sx2.y));
+                const float m = zr * zr + zi * zi;
+                const float eh = 0.5f * fmaf((float)N, s2, s1 * s1) * (1.f + 1e-5f), sq = __builtin_amdgcn_sqrtf(eh);
+                const float lim_s = (m - (err_lin * (__builtin_amdgcn_sqrtf(m) * sq) + err_sq * eh)) * keep;
+                if (m >= 1e-30f && eh <= 1e30f && eh * 1.005f - m * (1.f - 1e-5f) < lim_s) {
+                    if (wn < total) advance();
+                    pend_bin = sep_bin;
+                    pend_cls = lut_s[sep_bin];
+                    pend_mag = __builtin_amdgcn_sqrtf(m);
+                    pend_w = w;
+                    pend = true;
+                    ++sep_n;
+                    sep_done = true;
+                } else {
+                    // not decided after all (the pilot's column share said more than there was): the window comes
+                    // back and starts again, this time without this attempt
+                    refetch();
+                    next_off = off;
+                    sep_tried = true;
+                    continue;
+                }
+            }
+        }
+        do {
+        if (sep_done) break;
         Top3 best;
         float eproc;   // energy of the outputs this lane has looked at (each bin once)
         // What is still to do cannot matter once everything outside the outputs already seen
@@ -1142,15 +1267,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 }
             }
         }
-        auto refetch = [&]() {
-            // The window's buffer is by now being overwritten by the next window: wait for that
-            // DMA, fetch this window again (the long way then fetches the next window again).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            (void)fetch(cur_s, cur_w);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ++redone;
-        };
-        int path = one_tile ? 0 : (picked ? 5 : (need != ALL ? 1 : 2));   // PROF build only
+        path = one_tile ? 0 : (picked ? 5 : (need != ALL ? 1 : 2));
         if (one_tile) {
             // the pilot found the energy in one column tile: stage 1 and stage 2 of that tile only
             bool done = false;
@@ -1291,22 +1408,25 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             pend_cls = full ? 0u : (cand >= 2 ? (best.k2 & KEY_BIN) : cls);
             if (!full && cand == 3) pend_mag = __int_as_float((int)(best.k3 & KEY_BIN));
         }
+        } while (0);
+        sep_tried = false;
         lap(ic<4>{});
         if constexpr (PROF) {
             prof[12 + path] = prof[12 + path] + 1ull;
-            prof[19 + path] = prof[19 + path] + (prof_t - path_t0);
+            prof[20 + path] = prof[20 + path] + (prof_t - path_t0);
         }
         w = wn;
     }
     flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer into this workgroup's LDS is left in flight
-    if (lane == 0 && cells_done) {
+    if (lane == 0 && (cells_done | sep_n)) {
         atomicAdd(&stats[3], cells_done);
         atomicAdd(&stats[4], s1_units);
         if (redone) atomicAdd(&stats[5], redone);
         if (whole_n) atomicAdd(&stats[6], whole_n);
         if (two_n) atomicAdd(&stats[7], two_n);
         if (pick_n) atomicAdd(&stats[8], pick_n);
+        if (sep_n) atomicAdd(&stats[9], sep_n);
     }
     if constexpr (PROF) {
         // out_bin[0..6]: clocks/256 per phase (DMA wait, pilot of stage 1 and the column tiles' rough
@@ -1319,10 +1439,10 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             for (int i = 8; i < 12; ++i) out_bin[i + 1] = (int)(prof[i] >> 8);   // parts of the pilot: reads, folds, matrix instructions
             out_bin[7] = (int)((__builtin_amdgcn_s_memtime() - prof_c0) >> 8);
             out_bin[8] = (int)((__builtin_amdgcn_s_memrealtime() - prof_r0) >> 8);
-            // [13..19]: windows by the way they went, [20..26]: their clocks/256
-            for (int i = 0; i < 7; ++i) {
+            // [13..20]: windows by the way they went, [21..28]: their clocks/256
+            for (int i = 0; i < 8; ++i) {
                 out_bin[13 + i] = (int)prof[12 + i];
-                out_bin[20 + i] = (int)(prof[19 + i] >> 8);
+                out_bin[21 + i] = (int)(prof[20 + i] >> 8);
             }
         }
     }
@@ -1563,18 +1683,21 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     // 0.7 -> 0.25 %, 0.8 and 0.9 -> none, but more windows the whole way; 0.7 is the fastest
     // (again after the later changes: 30.0 / 29.8 / 29.6 / 30.1 / 30.5 ms at 0.6 / 0.65 / 0.7 / 0.75 / 0.8).
     const float share = ctx->detect_share;   // 0.7 unless WN_DETECT_SHARE said otherwise when the context was made
+    // the separator's bin (the nearest one), for schemes that have a separator inside the searched range
+    const int sep_bin = ctx->sep_bin;
+    const float sep_share = (sep_bin > 0 && sep_bin < ctx->n / 2) ? ctx->detect_sep_share : 0.f;
     // the profiling build leaves its clock counts in out_bin[0..8] and out_mag[16 .. 16 + 4*blocks):
     // launches whose result arrays are shorter than that run the ordinary build
     if (ctx->detect_profile && total >= 16 + 4 * blocks)
         hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS + 1024, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
-                           ctx->detect_pick_share, d_cls, d_mag, d_bin, stats);
+                           ctx->detect_pick_share, sep_bin, sep_share, ctx->detect_profile, d_cls, d_mag, d_bin, stats);
     else
         hipLaunchKernelGGL((detect_kernel<N1, N2, false>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
-                           ctx->detect_pick_share, d_cls, d_mag, d_bin, stats);
+                           ctx->detect_pick_share, sep_bin, sep_share, ctx->detect_profile, d_cls, d_mag, d_bin, stats);
     return wn_launch_check("detect_kernel");
 }
 

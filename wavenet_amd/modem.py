@@ -219,11 +219,11 @@ class Modem:
         `columns` also the spectrum columns whose second stage was computed, the (row tile,
         column) products of the first stage that were, and the windows that were done twice; with
         `paths` also the passes the long way (first stage of every column tile, or of all but the
-        weakest one), of them those that left the weakest column tile out, and the windows that
-        took one tile of sixteen chosen columns."""
+        weakest one), of them those that left the weakest column tile out, the windows that took
+        one tile of sixteen chosen columns, and the windows decided from the separator's bin alone."""
         out = (C.c_int64 * 10)()
         L.check(L.lib.wn_detect_stats(self._ctx, out, _stream()), "wn_detect_stats")
-        return list(out)[:9 if paths else (6 if columns else 3)]
+        return list(out)[:10 if paths else (6 if columns else 3)]
 
     def sync_scan(self, audio: torch.Tensor, n_streams: int, stream_stride: int, n_windows: int, first_sample: int = 0):
         """Ping correlator (the test of escuchar_ping, c1_shared.py:380-382) per window:
