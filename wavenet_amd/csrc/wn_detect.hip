@@ -47,9 +47,14 @@
 // magnitudes are still those of the whole spectrum.  Stage 1 starts with a pilot (one row tile
 // of every column tile) that says where the energy is: a window with nearly all of it in one
 // column tile gets stage 1 and stage 2 of that tile only, cell by cell (row tile x column
-// tile) with the check after each; other windows get all of stage 1 and stage 2 in the order
-// of the pilot's energies.  A window that fails the check after a one-tile pass is done again
-// the whole way.  LDS and global-memory instructions issue beside the wave's matrix
+// tile) with the check after each; a window with nearly all of it in a dozen columns of
+// different tiles (two tones meeting) gets one tile made of its sixteen strongest columns;
+// other windows get stage 1 of all tiles (or all but the weakest) and stage 2 in the order
+// of the pilot's energies.  A window that fails the check after a partial pass is done again
+// with more.  Before any of that, a window in which the pilot finds half of the energy in the
+// separator tone's column has that one bin computed alone (chunk sums on the vector ALU) and is
+// decided from it if the rest of the window's energy cannot compete: two windows in five of a
+// transmission.  LDS and global-memory instructions issue beside the wave's matrix
 // instructions (vector-ALU ones do not), so sample reads and the next window's DMA pieces are
 // placed one after each MFMA.
 //
