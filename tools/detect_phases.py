@@ -38,9 +38,11 @@ for what, audio in (("noise", 0.3 * torch.randn((S, stride), device="cuda")), ("
     for n, c in zip(names, v):
         print("  %-22s %8.0f clocks/window" % (n, c * 256.0 / nw))
     print("  %-22s %8.0f clocks/window" % ("total", v[7] * 256.0 / nw))
-    extra = kbin.view(-1)[9:12].tolist()
+    extra = kbin.view(-1)[9:13].tolist()
     print("  of the pilot: sample reads %.0f, folds %.0f, matrix instructions %.0f clocks/window"
-          % tuple(c * 256.0 / nw for c in extra))
+          % tuple(c * 256.0 / nw for c in extra[:3]))
+    print("  %-22s %8.0f clocks/window (chunk sums, next DMA, decision of the windows decided that way)"
+          % ("separator's bin alone", extra[3] * 256.0 / nw))
     ways = kbin.view(-1)[13:29].tolist()
     for i, name in enumerate(("one column tile", "long way, weakest tile left out", "long way, every tile",
                               "one tile, then the long way", "the long way twice", "sixteen chosen columns",

@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     pend = true;
                     ++sep_n;
                     sep_done = true;
+                    lap(ic<11>{});
                 } else {
                     // not decided after all (the pilot's column share said more than there was): the window comes
                     // back and starts again, this time without this attempt
