@@ -239,7 +239,7 @@ def noisy_detection(m, audio, n_streams, stride, nwin):
     m.awgn(audio, 0.1, 99)
     m.detect_stats()
     ms = timed_launches(lambda: m.detect(audio, n_streams, stride, nwin))
-    w, top2, full, cells, units, redone, whole, two, chosen, sep_alone = m.detect_stats(paths=True)
+    w, top2, full, cells, units, redone, whole, two, chosen, sep_alone, tone_alone = m.detect_stats(paths=True)
     cls, _, _ = m.detect(audio, n_streams, stride, nwin)
     by, ln, _, _, reason, _ = m.slice(cls, m.timeout_windows(123.0), 1, 128)
     rec = m.parse_frames(by.view(n_streams, 128), ln.view(-1)).cpu().numpy().view(M.REC_DTYPE).reshape(-1)
@@ -501,7 +501,7 @@ def main():
         win_per_launch = sub * nwin
         # flop of what the launches computed: stage 1 of every window, stage 2 of the spectrum
         # columns the kernel did not leave out (counted by the kernel itself over the timed steps)
-        st_windows, _, _, st_cells, st_units, st_redone, st_whole, st_two, st_chosen, st_sep = counters
+        st_windows, _, _, st_cells, st_units, st_redone, st_whole, st_two, st_chosen, st_sep, st_tone = counters
         s1_flop_per_unit, s1_units_full, s2_flop_per_unit, s2_units_full = detect_flop(n1, n2)
         cells_per_window = st_cells / max(st_windows, 1)
         units_per_window = st_units / max(st_windows, 1)
@@ -555,6 +555,7 @@ def main():
                          "of_them_without_the_weakest_column_tile": st_two / max(st_windows, 1),
                          "windows_on_sixteen_chosen_columns": st_chosen / max(st_windows, 1),
                          "windows_decided_from_the_separator_bin_alone": st_sep / max(st_windows, 1),
+                         "windows_decided_from_another_scheme_tone_bin_alone": st_tone / max(st_windows, 1),
                          "windows_done_twice": st_redone / max(st_windows, 1)},
             "synth": {"bound": "hbm", "kernel": "synth_kernel<float, false>", "ms_per_launch": syn_ms,
                       "algorithmic_bytes": sub * stride * 4,

@@ -130,11 +130,12 @@ int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
  * but the weakest) and had to be done again on more (their work is counted again in out[3],
  * out[4]), out[6] passes "the long way" (first stage of every column tile, or of all but the
  * weakest; those of out[5] included), out[7] of them those that left the weakest column tile out,
- * out[8] windows that took one tile of sixteen columns chosen for them; out[9] is reserved and
- * zero.  The rest was left out because the energy outside the outputs already seen could not reach
+ * out[8] windows that took one tile of sixteen columns chosen for them, out[9] windows decided from
+ * the separator's bin alone, out[10] windows decided from the bin of another tone of the scheme alone;
+ * out[11] is reserved and zero.  The rest was left out because the energy outside the outputs already seen could not reach
  * the decision threshold.  One set of counters per context, summed over every thread and stream
  * that detects with it. */
-int wn_detect_stats(wn_ctx *ctx, int64_t out[10], void *stream);
+int wn_detect_stats(wn_ctx *ctx, int64_t out[12], void *stream);
 
 /* ---- K4: checksum and frames ------------------------------------------------------- */
 /* calcular_checksum (B:178-187; A:89) over n messages: d_out[i] = zlib CRC-32 of

@@ -667,6 +667,60 @@ def test_detect_separator_bin_alone(monkeypatch, mb, golden):
             assert np.allclose(mag[0].cpu().numpy(), om, rtol=1e-4)
 
 
+def test_detect_scheme_tone_bin_alone(monkeypatch, mb, golden):
+    """Windows that hold little else than one tone of the scheme (a byte tone, the ping, the end
+    tone) are decided from that one bin: the pilot names the spectrum column, the swing of its row
+    sums names the tone among those of the column.  (a) Every byte tone, the ping and the end tone
+    alone, at a random start phase.  (b) Byte tones with the separator over the first 5 to 30 % of the
+    window, and with noise.  (c) Tones that are not the scheme's (35 Hz off): the wrong bin is tried,
+    the window starts again and goes the usual ways.  (d) Two byte tones of the same spectrum
+    column, the weaker one at 0.45 of the stronger.  Bins, classes and magnitudes are the oracle's;
+    with the test switched off the same windows give the same."""
+    lut = np.array(golden["classes_b_7055"], dtype=np.uint16)
+    rng = np.random.default_rng(89)
+    t = np.arange(7055)
+    tones = [350 + 70 * b for b in range(256)] + [250, 300]
+    col = lambda f: min(round(f * 7055 / 44100) % 85, 85 - round(f * 7055 / 44100) % 85)
+    windows = []
+    for f in tones:                                                                   # (a)
+        windows.append(0.5 * np.sin(2 * np.pi * f * (t + int(rng.integers(0, 5000))) / 44100))
+    for _ in range(60):                                                               # (b)
+        f = tones[int(rng.integers(0, 256))]
+        cut = int(7055 * rng.uniform(0.05, 0.30))
+        x = 0.5 * np.sin(2 * np.pi * 200 * t / 44100)
+        x[cut:] = 0.5 * np.sin(2 * np.pi * f * t[cut:] / 44100)
+        windows.append(x + 10 ** rng.uniform(-4, -1.3) * rng.standard_normal(7055))
+    for _ in range(40):                                                               # (c)
+        f = tones[int(rng.integers(0, 256))] + 35
+        windows.append(0.5 * np.sin(2 * np.pi * f * t / 44100 + rng.uniform(0, 6.28)))
+    same_col = [(f, g) for f in tones[:256] for g in tones[:256] if f < g and col(f) == col(g)]
+    for i in rng.choice(len(same_col), 40, replace=False):                            # (d)
+        f, g = same_col[int(i)]
+        windows.append(0.5 * np.sin(2 * np.pi * f * t / 44100) + 0.225 * np.sin(2 * np.pi * g * t / 44100 + 1.0))
+    n_windows = len(windows)
+    first = 2
+    stride = M.pad4(first + n_windows * 7055 + 5)
+    a = np.zeros((1, stride), dtype=np.float32)
+    for w, x in enumerate(windows):
+        a[0, first + w * 7055:first + (w + 1) * 7055] = x
+    monkeypatch.setenv("WN_DETECT_BIN", "0")
+    off = M.Modem(M.esquema_b())
+    ob, om, oc = oracle_windows(a[0, first:first + n_windows * 7055], lut, 7055)
+    for m, on in ((mb, True), (off, False)):
+        m.detect_stats()
+        cls, mag, kbin = m.detect(dev(a), 1, stride, n_windows, first)
+        st = m.detect_stats(paths=True)
+        assert st[0] == n_windows
+        if on:
+            assert st[10] >= 200                    # most of (a) and (b): a tone two fifths of a bin off its bin holds too little in it
+            assert st[5] >= 20                      # (c) came back from the test
+        else:
+            assert st[10] == 0
+        assert np.array_equal(kbin[0].cpu().numpy(), ob)
+        assert np.array_equal(cls[0].cpu().numpy().astype(np.uint16), oc)
+        assert np.allclose(mag[0].cpu().numpy(), om, rtol=1e-4)
+
+
 def test_detect_sixteen_chosen_columns(monkeypatch, mb, golden):
     """Windows whose energy sits in a few spectrum columns of different column tiles get one tile made
     of the sixteen strongest columns, with twiddles and bins worked out per window.  (a) The separator

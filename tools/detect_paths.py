@@ -13,4 +13,4 @@ m.detect_stats()
 m.detect(audio, S, stride, nwin); torch.cuda.synchronize()
 st = m.detect_stats(paths=True)
 w = st[0]
-print("windows %d: long-way passes %.4f, of them two-tile %.4f, sixteen chosen columns %.4f, separator bin alone %.4f, done twice %.4f, s1 units %.1f, s2 cells %.1f" % (w, st[6]/w, st[7]/w, st[8]/w, st[9]/w, st[5]/w, st[4]/w, st[3]/w))
+print("windows %d: long-way passes %.4f, of them two-tile %.4f, sixteen chosen columns %.4f, separator bin alone %.4f, another tone's bin alone %.4f, done twice %.4f, s1 units %.1f, s2 cells %.1f" % (w, st[6]/w, st[7]/w, st[8]/w, st[9]/w, st[10]/w, st[5]/w, st[4]/w, st[3]/w))

@@ -78,6 +78,6 @@ for name, esq, n in (("B", M.esquema_b(), 7055), ("A", M.esquema_a(), 2205)):
         done += k
     st = m.detect_stats(paths=True)
     print("scheme %s: %d windows, %d mismatches, %d with float64 ties left out; float64 candidates %d, float64 spectra %d, "
-          "stage-2 products per window %.1f, windows done twice %d, on sixteen chosen columns %d, from the separator's bin alone %d"
-          % (name, done, bad, unclear, st[1], st[2], st[3] / max(st[0], 1), st[5], st[8], st[9]), flush=True)
+          "stage-2 products per window %.1f, windows done twice %d, on sixteen chosen columns %d, from the separator's bin alone %d, from another scheme tone's bin alone %d"
+          % (name, done, bad, unclear, st[1], st[2], st[3] / max(st[0], 1), st[5], st[8], st[9], st[10]), flush=True)
     assert bad == 0

@@ -44,7 +44,7 @@ for sigma in (0.0, 0.03, 0.1, 0.3, 0.6, 1.0, 2.0):
         m.awgn(audio, sigma, 7)
     m.detect_stats()
     ms = timed(lambda: m.detect(audio, S, stride, nwin))
-    w, top2, full, cells, units, redone, whole, two, chosen, sep_alone = m.detect_stats(paths=True)
+    w, top2, full, cells, units, redone, whole, two, chosen, sep_alone, tone_alone = m.detect_stats(paths=True)
     cls, _, _ = m.detect(audio, S, stride, nwin)
     by, ln, _, _, _, _ = m.slice(cls, m.timeout_windows(123.0), 1, 128)
     rec = m.parse_frames(by.view(S, 128), ln.view(-1)).cpu().numpy().view(M.REC_DTYPE).reshape(-1)

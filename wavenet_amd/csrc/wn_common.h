@@ -20,7 +20,7 @@ struct wn_ctx {
     float2 *d_tw1;        // n1 entries (cos, sin)(2*pi*m/n1)
     float2 *d_tw2;        // n2 entries (cos, -sin)(2*pi*m/n2)
     double tie_band;
-    unsigned long long *d_stats;  // 16 counters (9 used)
+    unsigned long long *d_stats;  // 16 counters (11 used)
     // sync: ping bins [lo, hi]
     int32_t ping_lo, ping_hi;
     // checksum: slicing-by-4 tables [4][256]
@@ -32,6 +32,9 @@ struct wn_ctx {
     int detect_profile;
     float detect_share;    // share of the pilot's energy in one column tile that sends a window the one-tile way
     float detect_two_share;   // the weakest column tile is left out when the pilot finds at most this share in it (0: never)
+    int32_t *d_cand;          // the scheme's tones other than the separator by spectrum column: 8 entries each,
+                              // bin | folded row frequency << 16, 0 where there is none (null: not built)
+    float detect_bin_share;   // share of the pilot's energy in one column from which the fitting tone's bin is tried alone (0: never)
     int sep_bin;              // bin nearest to the separator tone (0: the scheme has none)
     float detect_sep_share;   // share of the pilot's energy in the separator's column from which that bin is tried alone (0: never)
     float detect_pick_share;  // class width of the choice of sixteen spectrum columns, as a share of the pilot's energy (0: never)

@@ -143,7 +143,16 @@ struct Plan {
     // then (cos, sin, -sin, cos) of exp(2*pi*i*kc*256*j/N) for every chunk j
     static constexpr int NCH = (N + 3 + 255) / 256;
     static constexpr int OFF_SEP = OFF_CB + ((K2 * 4 + 15) & ~15);
-    static constexpr int OFF_XW = OFF_SEP + 256 * 8 + NCH * 16;
+    // for the one-bin test of a scheme tone: cos(2*pi*m/n1); the scheme's tones by spectrum column (8 entries
+    // each: bin | folded row frequency << 16); exp(2*pi*i*128*a/N) and exp(2*pi*i*b/N), b < 128; one table
+    // of chunk factors per wave
+    static constexpr int NTH = (N + 127) / 128;
+    static constexpr int OFF_TW1C = OFF_SEP + 256 * 8 + NCH * 16;
+    static constexpr int OFF_CAND = OFF_TW1C + ((N1 * 4 + 15) & ~15);
+    static constexpr int OFF_TH = OFF_CAND + K2 * 8 * 4;
+    static constexpr int OFF_TL = OFF_TH + NTH * 8;
+    static constexpr int OFF_WU = OFF_TL + 128 * 8;
+    static constexpr int OFF_XW = OFF_WU + 4 * NCH * 16;
     static constexpr size_t LDS = (size_t)OFF_XW + (size_t)4 * XW * 4;
     // idempotents of the index map: bin of Z[j][k2] is (j*E1 + k2*E2) mod N
     static constexpr int idem(int own, int other) {
@@ -324,7 +333,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                                                         const float2 *__restrict__ g_tw2,
                                                         const uint16_t *__restrict__ lut, float keep,
                                                         float err_lin, float err_sq, float one_share, float two_share,
-                                                        float pick_share, int sep_bin, float sep_share, int prof_mode,
+                                                        float pick_share, int sep_bin, float sep_share,
+                                                        const int *__restrict__ g_cand, float bin_share, int prof_mode,
                                                         uint16_t *__restrict__ out_cls, float *__restrict__ out_mag,
                                                         int32_t *__restrict__ out_bin,
                                                         unsigned long long *__restrict__ stats) {
@@ -361,6 +371,18 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
 
     for (int i = threadIdx.x; i < N2; i += 256) ((float2 *)(smem + P::OFF_TW2))[i] = g_tw2[i];
     for (int i = threadIdx.x; i < P::K2; i += 256) ((int *)(smem + P::OFF_CB))[i] = (int)(((long long)i * P::E2) % N);
+    if (bin_share > 0.f) {
+        for (int i = threadIdx.x; i < N1; i += 256) ((float *)(smem + P::OFF_TW1C))[i] = g_tw1[i].x;
+        for (int i = threadIdx.x; i < P::K2 * 8; i += 256) ((int *)(smem + P::OFF_CAND))[i] = g_cand[i];
+        double sn, cs;
+        if (threadIdx.x < 128) {
+            sincospi(2.0 * (double)threadIdx.x / (double)N, &sn, &cs);
+            ((float2 *)(smem + P::OFF_TL))[threadIdx.x] = make_float2((float)cs, (float)sn);
+        } else if (threadIdx.x - 128 < P::NTH) {
+            sincospi(2.0 * (double)(128 * (threadIdx.x - 128)) / (double)N, &sn, &cs);
+            ((float2 *)(smem + P::OFF_TH))[threadIdx.x - 128] = make_float2((float)cs, (float)sn);
+        }
+    }
     if (sep_share > 0.f) {
         double sn, cs;
         sincospi(2.0 * (double)(((long long)sep_bin * threadIdx.x) % N) / (double)N, &sn, &cs);
@@ -601,6 +623,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     unsigned long long two_n = 0;       // of them: with one column tile left out
     unsigned long long pick_n = 0;      // windows that took sixteen chosen columns
     unsigned long long sep_n = 0;       // windows decided from the separator's bin alone
+    unsigned long long tone_n = 0;      // windows decided from the bin of another tone of the scheme alone
     int next_off = 0;
     bool sep_tried = false;   // this window has been through the separator's test and came back
     if (w < total) {
@@ -942,27 +965,101 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ++redone;
         };
-        // The separator alone.  Two windows in five hold little else than the separator tone, whose bin is
-        // known beforehand.  When the pilot finds nearly everything in that bin's column, the bin is
-        // computed by itself: per chunk of 256 samples every lane multiplies its four samples by
-        // fixed phase factors, the chunk's sum is turned by the chunk's own factor, and the window's
-        // energy is summed beside it (no matrix instructions, a tenth of the one-tile way).  If
-        // everything outside that bin holds less than the limit below which nothing can compete, the
-        // window is decided: same bound, same limit as after any part of the spectrum.  Otherwise the
-        // window goes on as if nothing had happened.
+        // One bin alone.  Two windows in five of a transmission hold little else than the separator tone,
+        // one in four little else than one data tone.  When the pilot finds half of its energy in the
+        // separator's column, or more than `bin_share` of it in one column that holds tones of the
+        // scheme, one bin is computed by itself: the separator's, or the scheme tone of that column whose
+        // row frequency fits the pilot's rows best (a tone makes the pilot's sixteen row sums S[a'] of a
+        // column swing like cos(2*pi*k1*a'/n1) against S[0]; every candidate's pattern is laid against
+        // them).  Per chunk of 256 samples every lane multiplies its four samples by fixed phase factors,
+        // the chunk's sum is turned by the chunk's own factor, and the window's energy is summed beside
+        // it (no matrix instructions, a tenth of the one-tile way).  If everything outside that bin
+        // holds less than the limit below which nothing can compete, the window is decided: same bound,
+        // same limit as after any part of the spectrum.  Otherwise the window starts again without
+        // this attempt.
         int path = 7;   // PROF build only
         bool sep_done = false;
         if constexpr (C2T > 2) {
             float tot = 0.f;
 #pragma unroll
             for (int c = 0; c < C2T; ++c) tot += __uint_as_float(eo[c]);
-            const int scol = min(sep_bin % N2, N2 - sep_bin % N2);   // the bin's spectrum column
-            const float in_tile = (scol >> 4) == 0 ? ec[0] : ((scol >> 4) == 1 ? ec[1] : ec[2]);
-            if (sep_share > 0.f && !sep_tried && tot <= 1e30f &&
-                lane63(wave_sum63(li == (scol & 15) ? in_tile : 0.f)) >= sep_share * tot) {
+            if (!sep_tried && tot <= 1e30f && (sep_share > 0.f || bin_share > 0.f)) {
+                int cand = 0;   // the bin to try, 0: none
+                bool is_sep = false;
+                floatx4 p01 = {0.f, 0.f, 0.f, 0.f}, p23 = p01;       // this lane's phase factors for floats 4*lane + q of a chunk
+                const floatx4 *utab = (const floatx4 *)(smem + P::OFF_SEP + 256 * 8);   // (cos, sin, -sin, cos) of the chunks' factors
+                const int scol = min(sep_bin % N2, N2 - sep_bin % N2);   // the separator bin's spectrum column
+                const float in_tile = (scol >> 4) == 0 ? ec[0] : ((scol >> 4) == 1 ? ec[1] : ec[2]);
+                if (sep_share > 0.f && lane63(wave_sum63(li == (scol & 15) ? in_tile : 0.f)) >= sep_share * tot) {
+                    cand = sep_bin;
+                    is_sep = true;
+                    p01 = ((const floatx4 *)(smem + P::OFF_SEP))[2 * lane];
+                    p23 = ((const floatx4 *)(smem + P::OFF_SEP))[2 * lane + 1];
+                } else if (bin_share > 0.f) {
+                    // the strongest column (lane 16c + li speaks for column 16c + li; computed from a copy of the
+                    // lane number the compiler cannot see through, see the choice of sixteen columns below)
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    float ce[C2T];
+#pragma unroll
+                    for (int c = 0; c < C2T; ++c) {
+                        const unsigned a = __float_as_uint(ec[c]);
+                        const auto h = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+                        const float s2 = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+                        const auto f = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+                        ce[c] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+                    }
+                    const int lgq = ln >> 4;
+                    const float mine = lgq == 0 ? ce[0] : (lgq == 1 ? ce[1] : ce[2]);
+                    const unsigned top = lane63(wave_max63(ln <= H2 ? ((__float_as_uint(mine) & ~63u) | (unsigned)ln) : 0u));
+                    const int cs = (int)(top & 63u);
+                    if (__uint_as_float(top & ~63u) >= bin_share * tot) {
+                        // S[a'] of that column: register r of lane (group g, column lane ls) of its tile holds row a' = 4r + g
+                        const int ct = cs >> 4, ls = cs & 15;
+                        const floatx4 yr = ct == 0 ? pr[0] : (ct == 1 ? pr[1] : pr[2]), yi = ct == 0 ? pi[0] : (ct == 1 ? pi[1] : pi[2]);
+                        const float r0 = lane_f(yr.x, ls), i0 = lane_f(yi.x, ls);
+                        const floatx4 g = yr * r0 + yi * i0;   // Re(S[a'] conj(S[0])), in the four lanes that hold the column
+                        // lane 4j + p lays candidate j against rows a' = p, p + 4, p + 8, p + 12 (all in lane group p)
+                        const int jc = (ln >> 2) & 7, pp = ln & 3;
+                        const int src = 4 * (ls + 16 * pp);
+                        const float g0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(g.x)));
+                        const float g1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(g.y)));
+                        const float g2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(g.z)));
+                        const float g3 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(g.w)));
+                        const int entry = ((const int *)(smem + P::OFF_CAND))[8 * cs + jc];   // bin | folded row frequency << 16
+                        const int k1f = entry >> 16;
+                        const float *cw = (const float *)(smem + P::OFF_TW1C);
+                        float sc = g0 * cw[(k1f * pp) % N1] + g1 * cw[(k1f * (pp + 4)) % N1] + g2 * cw[(k1f * (pp + 8)) % N1] +
+                                   g3 * cw[(k1f * (pp + 12)) % N1];
+                        sc += dpp_f0<0xB1, 0xF>(sc);
+                        sc += dpp_f0<0x4E, 0xF>(sc);
+                        unsigned u = __float_as_uint(sc);
+                        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // orders like the value
+                        const unsigned best_c = lane63(wave_max63((entry & 0xFFFF) && ln < 32 ? ((u & ~7u) | (unsigned)jc) : 0u));
+                        if (best_c) cand = ((const int *)(smem + P::OFF_CAND))[8 * cs + (int)(best_c & 7u)] & 0xFFFF;
+                    }
+                    if (cand) {
+                        // phase factors of that bin: exp(2*pi*i*m/N), m = cand * position mod N, as the product of two
+                        // table entries (m = 128a + b); this wave's chunk factors go to its own table
+                        auto turn = [&](unsigned m) {
+                            const float2 h = ((const float2 *)(smem + P::OFF_TH))[m >> 7], l = ((const float2 *)(smem + P::OFF_TL))[m & 127u];
+                            return make_float2(h.x * l.x - h.y * l.y, h.x * l.y + h.y * l.x);
+                        };
+                        const unsigned kc = (unsigned)cand;
+                        const float2 t0 = turn((kc * (4u * ln + 0u)) % (unsigned)N), t1 = turn((kc * (4u * ln + 1u)) % (unsigned)N);
+                        const float2 t2 = turn((kc * (4u * ln + 2u)) % (unsigned)N), t3 = turn((kc * (4u * ln + 3u)) % (unsigned)N);
+                        p01 = floatx4{t0.x, t0.y, t1.x, t1.y};
+                        p23 = floatx4{t2.x, t2.y, t3.x, t3.y};
+                        floatx4 *mine_u = (floatx4 *)(smem + P::OFF_WU) + P::NCH * wave;
+                        if (ln < P::NCH) {
+                            const float2 uj = turn((kc * 256u * (unsigned)ln) % (unsigned)N);
+                            mine_u[ln] = floatx4{uj.x, uj.y, -uj.y, uj.x};
+                        }
+                        utab = mine_u;
+                    }
+                }
+                if (cand) {
                 const floatx4 *buf = (const floatx4 *)(smf + xw_f) + lane;   // float 256*j + 4*lane + q of the buffer is sample 256*j + 4*lane + q - off
-                const floatx4 *utab = (const floatx4 *)(smem + P::OFF_SEP + 256 * 8);
-                const floatx4 p01 = ((const floatx4 *)(smem + P::OFF_SEP))[2 * lane], p23 = ((const floatx4 *)(smem + P::OFF_SEP))[2 * lane + 1];
                 const int off = next_off;
                 floatx2 acc = {0.f, 0.f}, e2 = {0.f, 0.f}, sx2 = {0.f, 0.f};
                 floatx4 xr[4], ur[4];
@@ -1004,35 +1101,30 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     asm volatile("" : "+v"(acc), "+v"(e2), "+v"(sx2));
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                // The next window's transfer starts as soon as the last chunk has been read (its values are in
-                // these sums), before the sums are collected: nothing else would run while it is under way.  A
-                // window that is not decided here after all is fetched again.
-                asm volatile("" ::"v"(acc), "v"(e2));
-                next_window_dma();
-                pend = false;
-                __builtin_amdgcn_sched_barrier(0);
                 const float zr = lane63(wave_sum63(acc.x)), zi = lane63(wave_sum63(acc.y));
                 const float s2 = lane63(wave_sum63(e2.x + e2.y)), s1 = lane63(wave_sum63(sx2.x + sx2.y));
                 const float m = zr * zr + zi * zi;
                 const float eh = 0.5f * fmaf((float)N, s2, s1 * s1) * (1.f + 1e-5f), sq = __builtin_amdgcn_sqrtf(eh);
                 const float lim_s = (m - (err_lin * (__builtin_amdgcn_sqrtf(m) * sq) + err_sq * eh)) * keep;
                 if (m >= 1e-30f && eh <= 1e30f && eh * 1.005f - m * (1.f - 1e-5f) < lim_s) {
+                    next_window_dma();
                     if (wn < total) advance();
-                    pend_bin = sep_bin;
-                    pend_cls = lut_s[sep_bin];
+                    pend_bin = cand;
+                    pend_cls = lut_s[cand];
                     pend_mag = __builtin_amdgcn_sqrtf(m);
                     pend_w = w;
                     pend = true;
-                    ++sep_n;
+                    if (is_sep) ++sep_n;
+                    else ++tone_n;
                     sep_done = true;
                     lap(ic<11>{});
                 } else {
-                    // not decided after all (the pilot's column share said more than there was): the window comes
-                    // back and starts again, this time without this attempt
-                    refetch();
-                    next_off = off;
+                    // not decided after all (the pilot sees a part of the rows): the window starts again,
+                    // this time without this attempt
+                    ++redone;
                     sep_tried = true;
                     continue;
+                }
                 }
             }
         }
@@ -1425,7 +1517,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     }
     flush();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer into this workgroup's LDS is left in flight
-    if (lane == 0 && (cells_done | sep_n)) {
+    if (lane == 0 && (cells_done | sep_n | tone_n)) {
         atomicAdd(&stats[3], cells_done);
         atomicAdd(&stats[4], s1_units);
         if (redone) atomicAdd(&stats[5], redone);
@@ -1433,6 +1525,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         if (two_n) atomicAdd(&stats[7], two_n);
         if (pick_n) atomicAdd(&stats[8], pick_n);
         if (sep_n) atomicAdd(&stats[9], sep_n);
+        if (tone_n) atomicAdd(&stats[10], tone_n);
     }
     if constexpr (PROF) {
         // out_bin[0..6]: clocks/256 per phase (DMA wait, pilot of stage 1 and the column tiles' rough
@@ -1692,18 +1785,19 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     // the separator's bin (the nearest one), for schemes that have a separator inside the searched range
     const int sep_bin = ctx->sep_bin;
     const float sep_share = (sep_bin > 0 && sep_bin < ctx->n / 2) ? ctx->detect_sep_share : 0.f;
+    const float bin_share = ctx->d_cand ? ctx->detect_bin_share : 0.f;
     // the profiling build leaves its clock counts in out_bin[0..8] and out_mag[16 .. 16 + 4*blocks):
     // launches whose result arrays are shorter than that run the ordinary build
     if (ctx->detect_profile && total >= 16 + 4 * blocks)
         hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS + 1024, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
-                           ctx->detect_pick_share, sep_bin, sep_share, ctx->detect_profile, d_cls, d_mag, d_bin, stats);
+                           ctx->detect_pick_share, sep_bin, sep_share, ctx->d_cand, bin_share, ctx->detect_profile, d_cls, d_mag, d_bin, stats);
     else
         hipLaunchKernelGGL((detect_kernel<N1, N2, false>), dim3((unsigned)blocks), dim3(256), P::LDS, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
-                           ctx->detect_pick_share, sep_bin, sep_share, ctx->detect_profile, d_cls, d_mag, d_bin, stats);
+                           ctx->detect_pick_share, sep_bin, sep_share, ctx->d_cand, bin_share, ctx->detect_profile, d_cls, d_mag, d_bin, stats);
     return wn_launch_check("detect_kernel");
 }
 

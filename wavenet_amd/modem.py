@@ -220,10 +220,11 @@ class Modem:
         column) products of the first stage that were, and the windows that were done twice; with
         `paths` also the passes the long way (first stage of every column tile, or of all but the
         weakest one), of them those that left the weakest column tile out, the windows that took
-        one tile of sixteen chosen columns, and the windows decided from the separator's bin alone."""
-        out = (C.c_int64 * 10)()
+        one tile of sixteen chosen columns, the windows decided from the separator's bin alone and
+        those decided from the bin of another tone of the scheme alone."""
+        out = (C.c_int64 * 12)()
         L.check(L.lib.wn_detect_stats(self._ctx, out, _stream()), "wn_detect_stats")
-        return list(out)[:10 if paths else (6 if columns else 3)]
+        return list(out)[:11 if paths else (6 if columns else 3)]
 
     def sync_scan(self, audio: torch.Tensor, n_streams: int, stream_stride: int, n_windows: int, first_sample: int = 0):
         """Ping correlator (the test of escuchar_ping, c1_shared.py:380-382) per window:
