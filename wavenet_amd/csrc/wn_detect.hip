@@ -979,7 +979,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         // this attempt.
         int path = 7;   // PROF build only
         bool sep_done = false;
-        if constexpr (C2T > 2) {
+        {
             float tot = 0.f;
 #pragma unroll
             for (int c = 0; c < C2T; ++c) tot += __uint_as_float(eo[c]);
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 floatx4 p01 = {0.f, 0.f, 0.f, 0.f}, p23 = p01;       // this lane's phase factors for floats 4*lane + q of a chunk
                 const floatx4 *utab = (const floatx4 *)(smem + P::OFF_SEP + 256 * 8);   // (cos, sin, -sin, cos) of the chunks' factors
                 const int scol = min(sep_bin % N2, N2 - sep_bin % N2);   // the separator bin's spectrum column
-                const float in_tile = (scol >> 4) == 0 ? ec[0] : ((scol >> 4) == 1 ? ec[1] : ec[2]);
+                const float in_tile = (scol >> 4) == 0 ? ec[0] : ((scol >> 4) == 1 ? ec[1] : ec[C2T - 1]);
                 if (sep_share > 0.f && lane63(wave_sum63(li == (scol & 15) ? in_tile : 0.f)) >= sep_share * tot) {
                     cand = sep_bin;
                     is_sep = true;
@@ -1010,13 +1010,13 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                         ce[c] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
                     }
                     const int lgq = ln >> 4;
-                    const float mine = lgq == 0 ? ce[0] : (lgq == 1 ? ce[1] : ce[2]);
+                    const float mine = lgq == 0 ? ce[0] : (lgq == 1 ? ce[1] : ce[C2T - 1]);
                     const unsigned top = lane63(wave_max63(ln <= H2 ? ((__float_as_uint(mine) & ~63u) | (unsigned)ln) : 0u));
                     const int cs = (int)(top & 63u);
                     if (__uint_as_float(top & ~63u) >= bin_share * tot) {
                         // S[a'] of that column: register r of lane (group g, column lane ls) of its tile holds row a' = 4r + g
                         const int ct = cs >> 4, ls = cs & 15;
-                        const floatx4 yr = ct == 0 ? pr[0] : (ct == 1 ? pr[1] : pr[2]), yi = ct == 0 ? pi[0] : (ct == 1 ? pi[1] : pi[2]);
+                        const floatx4 yr = ct == 0 ? pr[0] : (ct == 1 ? pr[1] : pr[C2T - 1]), yi = ct == 0 ? pi[0] : (ct == 1 ? pi[1] : pi[C2T - 1]);
                         const float r0 = lane_f(yr.x, ls), i0 = lane_f(yi.x, ls);
                         const floatx4 g = yr * r0 + yi * i0;   // Re(S[a'] conj(S[0])), in the four lanes that hold the column
                         // lane 4j + p lays candidate j against rows a' = p, p + 4, p + 8, p + 12 (all in lane group p)
