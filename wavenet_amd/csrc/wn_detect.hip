@@ -51,10 +51,11 @@
 // different tiles (two tones meeting) gets one tile made of its sixteen strongest columns;
 // other windows get stage 1 of all tiles (or all but the weakest) and stage 2 in the order
 // of the pilot's energies.  A window that fails the check after a partial pass is done again
-// with more.  Before any of that, a window in which the pilot finds half of the energy in the
-// separator tone's column has that one bin computed alone (chunk sums on the vector ALU) and is
-// decided from it if the rest of the window's energy cannot compete: two windows in five of a
-// transmission.  LDS and global-memory instructions issue beside the wave's matrix
+// with more.  Before any of that, a window in which the pilot finds most of the energy in the
+// column of the separator tone, or in a column that holds other tones of the scheme, has one bin
+// computed alone (the separator's, or that of the tone whose row frequency fits the pilot's rows;
+// chunk sums on the vector ALU) and is decided from it if the rest of the window's energy cannot
+// compete: three windows in five of a transmission.  LDS and global-memory instructions issue beside the wave's matrix
 // instructions (vector-ALU ones do not), so sample reads and the next window's DMA pieces are
 // placed one after each MFMA.
 //
