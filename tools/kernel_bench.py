@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10_000_000)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--only", default="synth,sync,detect,crc,long,protoA")
+    ap.add_argument("--messages", type=int, default=20000, help="messages of the prototype scheme (1.13 MB of audio each)")
     args = ap.parse_args()
     only = set(args.only.split(","))
     m = M.Modem(M.esquema_b())
@@ -175,7 +176,7 @@ def main():
 
     if "protoA" in only:
         ma = M.Modem(M.esquema_a())
-        n, msg = 20000, 127
+        n, msg = args.messages, 127
         g = torch.Generator().manual_seed(4)
         rows = torch.randint(0, 128, (n, 128), dtype=torch.uint8, generator=g).cuda()
         lens_a = torch.full((n,), msg, dtype=torch.int32, device="cuda")
@@ -194,9 +195,9 @@ def main():
         ta = (h1 + 15) // 16
         flop = (2.0 * n1 * h2 * h2 * 2 * (st[4] / max(st[0], 1)) / (4 * ta * h2)
                 + 2.0 * h1 * h1 * 4 * h2 * (st[3] / max(st[0], 1)) / (ta * h2)) * n * nw
-        out.append({"kernel": "prototype scheme: synth / detect_kernel<45,49>", "synth_ms": mean_s,
+        out.append({"kernel": "prototype scheme: synth / detect_kernel<45,49>", "messages": n, "synth_ms": mean_s,
                     "synth_GBps": n * stride_a * 4 / mean_s / 1e6, "detect_ms": mean_d,
-                    "detect_TFLOPs": flop / mean_d / 1e9, "detect_frac_f32_mfma": flop / mean_d / 1e9 / 157.3,
+                    "detect_GBps": n * nw * (win_a * 4 + 10) / mean_d / 1e6, "detect_TFLOPs": flop / mean_d / 1e9, "detect_frac_f32_mfma": flop / mean_d / 1e9 / 157.3,
                     "windows": n * nw, "stage2_tile_columns_computed_per_window": st[3] / max(st[0], 1), "stage2_tile_columns_per_window": ta * h2,
                     "bytes_exact": ok})
 
