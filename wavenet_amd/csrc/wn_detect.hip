@@ -83,6 +83,12 @@
 // 1: the pilot keeps the folded operands of row-tile pair 0 for stage 1 (44 more registers, 509 of
 // a SIMD lane's 512 in all: about 1.5 % faster alone); 0: stage 1 gathers and folds that pair again
 // (448 registers, which leaves room on every SIMD for a wave of a small kernel on another stream).
+// 1: the circular extension of a window (its first samples again behind its last) is copied inside LDS
+// when the window has landed; 0: it is fetched a second time by 4-byte DMA pieces (thirteen more memory
+// instructions per window: about 1 % slower on the round trip)
+#ifndef WN_EXT_COPY
+#define WN_EXT_COPY 1
+#endif
 #ifndef WN_DETECT_KEEP0
 #define WN_DETECT_KEEP0 1
 #endif
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         const int i0 = P::SM + lane - off;
         dma_group<1, 256, false>(x0 + (i0 < N ? i0 : i0 - N), __builtin_amdgcn_readfirstlane(lds_base + 4u * P::SM));
         const float *ext = x0 + (P::SM + 64 + lane - off - N);
-        static_for<(P::NDW - 1 + 3) / 4>([&](auto G) {
+        if constexpr (!WN_EXT_COPY) static_for<(P::NDW - 1 + 3) / 4>([&](auto G) {
             constexpr int g = decltype(G)::value, cnt = P::NDW - 1 - 4 * g < 4 ? P::NDW - 1 - 4 * g : 4;
             dma_group<cnt, 256, false>(ext + 256 * g,
                                        __builtin_amdgcn_readfirstlane(lds_base + 4u * (P::SM + 64) + 1024u * g));
@@ -551,13 +557,24 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
         if constexpr (k < DMA_FULL) {
             if constexpr (k % 4 == 0) wn_m0_set(__builtin_amdgcn_readfirstlane(lds_base + 4096u * (k / 4)));
             dma_piece<1024 * (k % 4), true>(nx_src + 1024 * (k / 4), 16u * lane);
-        } else if constexpr (k < DMA_PIECES) {
+        } else if constexpr (k < DMA_PIECES && !WN_EXT_COPY) {
             constexpr int j = k - DMA_FULL;
             if constexpr (j % 4 == 0)
                 wn_m0_set(__builtin_amdgcn_readfirstlane(lds_base + 4u * (P::SM + 64) + 1024u * (j / 4)));
             dma_piece<256 * (j % 4), false>(nx_ext + 256 * (j / 4), 4u * lane);
         }
         if constexpr (k == DMA_PIECES - 1) wn_m0_set(m0_keep);
+    };
+    auto extend = [&]() {
+        if constexpr (WN_EXT_COPY) {
+            // float f of the buffer holds sample f - off; the extension repeats samples 0 .. from float off + N on
+            float *bufw = smf + xw_f;
+            float keepf[P::NDW - 1];
+#pragma unroll
+            for (int j = 0; j < P::NDW - 1; ++j) keepf[j] = bufw[P::SM + 64 + 64 * j + lane - N];
+#pragma unroll
+            for (int j = 0; j < P::NDW - 1; ++j) bufw[P::SM + 64 + 64 * j + lane] = keepf[j];
+        }
     };
     // (stream, window) of the window in work and of the one after it, advanced without divisions
     const long long adv_s = wstep / n_windows, adv_w = wstep - adv_s * n_windows;
@@ -641,6 +658,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             ad_m[t] = xb + cb_m[t];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this window's DMA has landed
+        extend();
         lap(ic<0>{});
 
         // ------------------------------------------------------------------ stage 1
@@ -964,6 +982,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             (void)fetch(cur_s, cur_w);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            extend();
             ++redone;
         };
         // One bin alone.  Two windows in five of a transmission hold little else than the separator tone,
