@@ -126,8 +126,8 @@ int wn_detect_set_tie_band(wn_ctx *ctx, double rel);
  * (n2+1)/2 columns k mod n2, folded, per window at most),
  * out[4] (row tile of 16, real or imaginary part, column) products of the first stage
  * (((n1+1)/2 + 15)/16*2 tiles times 2 times (n2+1)/2 columns per window at most), out[5] windows
- * that were started on part of the columns (one column tile, sixteen chosen columns, or all tiles
- * but the weakest) and had to be done again on more (their work is counted again in out[3],
+ * that were started on part of the spectrum (one bin, one column tile, sixteen chosen columns, or all
+ * tiles but the weakest) and had to be done again on more (their work is counted again in out[3],
  * out[4]), out[6] passes "the long way" (first stage of every column tile, or of all but the
  * weakest; those of out[5] included), out[7] of them those that left the weakest column tile out,
  * out[8] windows that took one tile of sixteen columns chosen for them, out[9] windows decided from

@@ -89,6 +89,12 @@
 #ifndef WN_EXT_COPY
 #define WN_EXT_COPY 1
 #endif
+// 1: while one bin is computed alone, the next window's transfer follows the chunk reads piece by piece
+// (a window that is not decided that way after all has to be fetched again); 0: the transfer starts when
+// the window is decided (about 3 % slower on the round trip: the transfers of a CU then come in bursts)
+#ifndef WN_BIN_PIPE
+#define WN_BIN_PIPE 1
+#endif
 #ifndef WN_DETECT_KEEP0
 #define WN_DETECT_KEEP0 1
 #endif
@@ -536,19 +542,24 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
     static_assert(DMA_PIECES <= 4 * KS2, "one piece per matrix instruction of a cell");
     const float *nx_src = audio, *nx_ext = audio;
     unsigned m0_keep = 0;
-    auto fetch_prepare = [&](long long s, long long wi) {
-        const long long g0 = s * stream_stride + first_sample + wi * (long long)N;
-        const int off = (int)(g0 & 3);
-        const float *x0 = audio + g0;
-        nx_src = x0 - off;
-        nx_ext = x0 + (P::SM + 64 - off - N);
+    // (the two pieces that need per-lane handling land in the last 256 floats a window occupies: a caller that
+    // is still reading there issues them afterwards, with fetch_late)
+    auto fetch_late = [&](int off) {
         if constexpr (DMA_REM > 0) {
             if (lane < DMA_REM)
                 dma_group<1, 1024, true>(nx_src + 4 * lane + 256 * DMA_FULL,
                                          __builtin_amdgcn_readfirstlane(lds_base + 1024u * DMA_FULL));
         }
         const int i0 = P::SM + lane - off;
-        dma_group<1, 256, false>(x0 + (i0 < N ? i0 : i0 - N), __builtin_amdgcn_readfirstlane(lds_base + 4u * P::SM));
+        dma_group<1, 256, false>(nx_src + off + (i0 < N ? i0 : i0 - N), __builtin_amdgcn_readfirstlane(lds_base + 4u * P::SM));
+    };
+    auto fetch_prepare = [&](long long s, long long wi, auto LATE) {
+        const long long g0 = s * stream_stride + first_sample + wi * (long long)N;
+        const int off = (int)(g0 & 3);
+        const float *x0 = audio + g0;
+        nx_src = x0 - off;
+        nx_ext = x0 + (P::SM + 64 - off - N);
+        if constexpr (!decltype(LATE)::value) fetch_late(off);
         m0_keep = wn_m0_get();
         return off;
     };
@@ -1081,6 +1092,17 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 if (cand) {
                 const floatx4 *buf = (const floatx4 *)(smf + xw_f) + lane;   // float 256*j + 4*lane + q of the buffer is sample 256*j + 4*lane + q - off
                 const int off = next_off;
+                if constexpr (WN_BIN_PIPE) {
+                    // The next window's transfer follows the reads chunk by chunk (a 16-byte piece of it covers
+                    // exactly one chunk; the pieces that land in the last chunk go out after the loop): the wave
+                    // has one window buffer and nothing else to do while the next window is under way.
+                    static_assert(DMA_FULL >= P::NCH - 1 && P::SM >= 256 * (P::NCH - 1),
+                                  "every piece from the last chunk's on lands in or behind the last chunk");
+                    flush();
+                    pend = false;
+                    const bool nxt = wn < total;
+                    next_off = fetch_prepare(nxt ? f_s : cur_s, nxt ? f_w : cur_w, ic<1>{});
+                }
                 floatx2 acc = {0.f, 0.f}, e2 = {0.f, 0.f}, sx2 = {0.f, 0.f};
                 floatx4 xr[4], ur[4];
                 auto ld = [&](auto J) {
@@ -1120,14 +1142,23 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     // and adds them up after the loop)
                     asm volatile("" : "+v"(acc), "+v"(e2), "+v"(sx2));
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (WN_BIN_PIPE && j < DMA_FULL && j < P::NCH - 1) {
+                        fetch_piece(ic<j>{});   // chunk j has been read (its values are in the sums pinned above)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 });
+                if constexpr (WN_BIN_PIPE) {
+                    static_for<DMA_PIECES - (P::NCH - 1)>([&](auto K) { fetch_piece(ic<P::NCH - 1 + decltype(K)::value>{}); });
+                    fetch_late(next_off);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const float zr = lane63(wave_sum63(acc.x)), zi = lane63(wave_sum63(acc.y));
                 const float s2 = lane63(wave_sum63(e2.x + e2.y)), s1 = lane63(wave_sum63(sx2.x + sx2.y));
                 const float m = zr * zr + zi * zi;
                 const float eh = 0.5f * fmaf((float)N, s2, s1 * s1) * (1.f + 1e-5f), sq = __builtin_amdgcn_sqrtf(eh);
                 const float lim_s = (m - (err_lin * (__builtin_amdgcn_sqrtf(m) * sq) + err_sq * eh)) * keep;
                 if (m >= 1e-30f && eh <= 1e30f && eh * 1.005f - m * (1.f - 1e-5f) < lim_s) {
-                    next_window_dma();
+                    if constexpr (!WN_BIN_PIPE) next_window_dma();
                     if (wn < total) advance();
                     pend_bin = cand;
                     pend_cls = lut_s[cand];
@@ -1141,7 +1172,12 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 } else {
                     // not decided after all (the pilot sees a part of the rows): the window starts again,
                     // this time without this attempt
-                    ++redone;
+                    if constexpr (WN_BIN_PIPE) {
+                        refetch();
+                        next_off = off;
+                    } else {
+                        ++redone;
+                    }
                     sep_tried = true;
                     continue;
                 }
@@ -1291,7 +1327,7 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 // a next window fetches this one again (the data is not used)
                 flush();
                 const bool nxt = wn < total;
-                next_off = fetch_prepare(nxt ? f_s : cur_s, nxt ? f_w : cur_w);
+                next_off = fetch_prepare(nxt ? f_s : cur_s, nxt ? f_w : cur_w, ic<0>{});
             } else {
                 next_window_dma();
             }
