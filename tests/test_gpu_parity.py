@@ -721,6 +721,38 @@ def test_detect_scheme_tone_bin_alone(monkeypatch, mb, golden):
         assert np.allclose(mag[0].cpu().numpy(), om, rtol=1e-4)
 
 
+@pytest.mark.parametrize("base, step, sep", [(410, 5, 180), (300, 37, 0), (1000, 64, 2210)])
+def test_detect_other_tone_plans(base, step, sep):
+    """The one-bin tests are driven by tables made from the scheme's tone plan when a context is made.
+    Plans other than the reference's: tones less than a bin apart (several share a bin, more than
+    eight fall in one spectrum column), a plan without a separator, a plan whose separator lies
+    among the byte tones.  Each tone alone, each with the separator (or its neighbour tone) over part
+    of the window, and noise: bins and magnitudes are NumPy's, classes the host table's."""
+    esq = M.esquema_b()
+    esq = type(esq)(**{**esq.__dict__, "nombre": "X", "base_freq": base, "freq_step": step, "sep_freq": sep,
+                       "ping_freq": 230 if sep else 0, "ping_n": esq.ping_n if sep else 0,
+                       "sep_n": esq.sep_n if sep else 0, "sep_short_n": esq.sep_short_n if sep else 0})
+    m = M.Modem(esq)
+    lut = M.host_class_lut(esq)
+    rng = np.random.default_rng(base + step)
+    t = np.arange(7055)
+    tones = [base + step * b for b in range(0, 256, 3)] + [esq.eof_freq] + ([sep, 230] if sep else [])
+    windows = []
+    for f in tones:
+        windows.append(0.4 * np.sin(2 * np.pi * f * (t + int(rng.integers(0, 3000))) / 44100))
+        other = sep if sep else tones[int(rng.integers(0, len(tones)))]
+        cut = int(7055 * rng.uniform(0.05, 0.95))
+        x = 0.4 * np.sin(2 * np.pi * other * t / 44100)
+        x[cut:] = 0.4 * np.sin(2 * np.pi * f * t[cut:] / 44100)
+        windows.append(x + 10 ** rng.uniform(-4, -1.5) * rng.standard_normal(7055))
+    windows.append(0.2 * rng.standard_normal(7055))
+    x32 = np.concatenate(windows).astype(np.float32)
+    m.detect_stats()
+    check_detect(m, x32, 7055, lut)
+    st = m.detect_stats(paths=True)
+    assert st[0] == len(windows) and st[9] + st[10] >= len(tones) // 3     # the one-bin tests did decide windows of this plan
+
+
 def test_detect_sixteen_chosen_columns(monkeypatch, mb, golden):
     """Windows whose energy sits in a few spectrum columns of different column tiles get one tile made
     of the sixteen strongest columns, with twiddles and bins worked out per window.  (a) The separator
