@@ -968,7 +968,23 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
             const floatx4 yr = pr[c], yi = pi[c];
             ec[c] = (yr.x * yr.x + yi.x * yi.x) + (yr.y * yr.y + yi.y * yi.y) + (yr.z * yr.z + yi.z * yi.z) +
                     (yr.w * yr.w + yi.w * yi.w);
-            eo[c] = lane63(__float_as_uint(wave_sum63(ec[c])));   // non-negative floats order like their bits
+        }
+        // per column (the four lane groups summed by two lane swaps: every lane then holds the energy of column
+        // 16c + li), then per tile (the sixteen columns of a row of lanes)
+        float ce[C2T];
+#pragma unroll
+        for (int c = 0; c < C2T; ++c) {
+            const unsigned a = __float_as_uint(ec[c]);
+            const auto h = __builtin_amdgcn_permlane16_swap(a, a, false, false);      // rows (0, 0, 2, 2) and (1, 1, 3, 3)
+            const float s2 = __uint_as_float(h[0]) + __uint_as_float(h[1]);
+            const auto f = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+            ce[c] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
+            float v = ce[c];
+            v += dpp_f0<0xB1, 0xF>(v);
+            v += dpp_f0<0x4E, 0xF>(v);
+            v += dpp_f0<0x141, 0xF>(v);
+            v += dpp_f0<0x140, 0xF>(v);
+            eo[c] = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v));   // non-negative floats order like their bits
         }
         int c_first = 0;
         bool one_tile;
@@ -1020,8 +1036,8 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                 floatx4 p01 = {0.f, 0.f, 0.f, 0.f}, p23 = p01;       // this lane's phase factors for floats 4*lane + q of a chunk
                 const floatx4 *utab = (const floatx4 *)(smem + P::OFF_SEP + 256 * 8);   // (cos, sin, -sin, cos) of the chunks' factors
                 const int scol = min(sep_bin % N2, N2 - sep_bin % N2);   // the separator bin's spectrum column
-                const float in_tile = (scol >> 4) == 0 ? ec[0] : ((scol >> 4) == 1 ? ec[1] : ec[C2T - 1]);
-                if (sep_share > 0.f && lane63(wave_sum63(li == (scol & 15) ? in_tile : 0.f)) >= sep_share * tot) {
+                const float in_tile = (scol >> 4) == 0 ? ce[0] : ((scol >> 4) == 1 ? ce[1] : ce[C2T - 1]);
+                if (sep_share > 0.f && lane_f(in_tile, scol & 15) >= sep_share * tot) {
                     cand = sep_bin;
                     is_sep = true;
                     p01 = ((const floatx4 *)(smem + P::OFF_SEP))[2 * lane];
@@ -1031,15 +1047,6 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
                     // lane number the compiler cannot see through, see the choice of sixteen columns below)
                     int ln = lane;
                     asm volatile("" : "+v"(ln));
-                    float ce[C2T];
-#pragma unroll
-                    for (int c = 0; c < C2T; ++c) {
-                        const unsigned a = __float_as_uint(ec[c]);
-                        const auto h = __builtin_amdgcn_permlane16_swap(a, a, false, false);
-                        const float s2 = __uint_as_float(h[0]) + __uint_as_float(h[1]);
-                        const auto f = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
-                        ce[c] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
-                    }
                     const int lgq = ln >> 4;
                     const float mine = lgq == 0 ? ce[0] : (lgq == 1 ? ce[1] : ce[C2T - 1]);
                     const unsigned top = lane63(wave_max63(ln <= H2 ? ((__float_as_uint(mine) & ~63u) | (unsigned)ln) : 0u));
@@ -1376,15 +1383,6 @@ __global__ __launch_bounds__(256, 1) void detect_kernel(const float *__restrict_
 #pragma unroll
             for (int c = 0; c < C2T; ++c) tot += __uint_as_float(eo[c]);
             if (!one_tile && pick_share > 0.f && tot <= 1e30f) {
-                float ce[C2T];
-#pragma unroll
-                for (int c = 0; c < C2T; ++c) {
-                    const unsigned a = __float_as_uint(ec[c]);
-                    const auto h = __builtin_amdgcn_permlane16_swap(a, a, false, false);      // rows (0, 0, 2, 2) and (1, 1, 3, 3)
-                    const float s2 = __uint_as_float(h[0]) + __uint_as_float(h[1]);
-                    const auto f = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
-                    ce[c] = __uint_as_float(f[0]) + __uint_as_float(f[1]);
-                }
                 // lane 16c + li speaks for column k2 = 16c + li.  (What follows is computed from a copy of the
                 // lane number the compiler cannot see through: left to itself it keeps a dozen per-lane
                 // constants of this rarely used block in registers for the whole launch.)
