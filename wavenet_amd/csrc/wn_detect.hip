@@ -1840,9 +1840,9 @@ static int launch_detect(wn_ctx *ctx, const float *d_audio, int64_t audio_len, i
     const int sep_bin = ctx->sep_bin;
     const float sep_share = (sep_bin > 0 && sep_bin < ctx->n / 2) ? ctx->detect_sep_share : 0.f;
     const float bin_share = ctx->d_cand ? ctx->detect_bin_share : 0.f;
-    // the profiling build leaves its clock counts in out_bin[0..8] and out_mag[16 .. 16 + 4*blocks):
+    // the profiling build leaves its clock counts in out_bin[0..28] and out_mag[16 .. 16 + 4*blocks):
     // launches whose result arrays are shorter than that run the ordinary build
-    if (ctx->detect_profile && total >= 16 + 4 * blocks)
+    if (ctx->detect_profile && total >= 32 + 4 * blocks)
         hipLaunchKernelGGL((detect_kernel<N1, N2, true>), dim3((unsigned)blocks), dim3(256), P::LDS + 1024, st, d_audio,
                            (long long)n_streams, (long long)stream_stride, (long long)first_sample,
                            (long long)n_windows, ctx->d_tw1, ctx->d_tw2, ctx->d_cls_lut, (float)k, err_lin, err_sq, share, ctx->detect_two_share,
